@@ -1,0 +1,208 @@
+/*
+ * cilqr.h — C-ABI of the MI355X-native batched constrained-iLQR (CILQR) solver and costmap warp.
+ *
+ * Drop-in boundary for the hot path of Leo-Liao-Chao/Uncertainty-Aware-CILQR-for-Trajectory-Optimization.
+ * All citations are relative to the reference tree, with I/ = CILQR/src/ilqr/include/ilqr/,
+ * M/ = CILQR/src/map_engine/, G/ = CILQR/src/grid_map/.
+ *
+ * The reference has no FFI layer: the planner node calls C++ methods on a stateful `iLQR` object
+ * (I/iLQR.h:16-59).  This header is what a binding for that path would bind instead:
+ *
+ *   reference interface                                      replaced by
+ *   -------------------------------------------------------  ------------------------------------
+ *   Parameters::Parameters()            I/Parameters.cpp:3-75   cilqr_params_default
+ *   iLQR::iLQR(const Parameters&)       I/iLQR.cpp:3-19         cilqr_create (+ cilqr_default_control_seq)
+ *   iLQR::get_optimal_control_seq       I/iLQR.cpp:201-245      cilqr_solve_batch / cilqr_solve_batch_device
+ *   iLQR::set_Obstacle / clear_Obstacle I/iLQR.cpp:20-27        obs_* arguments of cilqr_solve_batch (M = 0 ⇒ cleared)
+ *   Constraints::get_J                  I/Constraints.cpp:534-561   J_out of cilqr_solve_batch
+ *   LocalPlanner::get_local_plan(_coeffs) I/LocalPlanner.cpp:25-117 cilqr_local_plan (host pre-step)
+ *   LocalCostmap::odomCallback warp loop M/src/local_costmap.cpp:242-264 cilqr_warp_costmap(_device)
+ *   (none: batch min-cost selection is new)      cilqr_argmin_device
+ *
+ * Conventions
+ *   - fp64 everywhere in the solver; float32 map payloads in the warp.
+ *   - Per-solve layouts equal Eigen column-major as used by the reference and by
+ *     vehiclepub/Experiment.msg flattening (I/ilqr_uncertainty_node.cpp:265-274):
+ *       U  : [a0, w0, a1, w1, ...]               2*N doubles
+ *       X  : [x0, y0, v0, th0, x1, ...]          4*(N+1) doubles
+ *       obstacle pose (relative_pos_array, I/Obstacle.h:25) : 4*N doubles, column t = (x, y, v, theta)
+ *       obstacle dimension (I/Obstacle.h:24)                : 2*N doubles, column t = (length, width)
+ *     The batch index is outermost, then (for obstacle tables) the obstacle index.
+ *   - Every function returns 0 on success and a negative cilqr_status on failure; the message is
+ *     available from cilqr_last_error() (thread-local).  Nothing is printed to stdout.
+ *   - One handle = one device = one host thread at a time (the reference solver is not re-entrant
+ *     either: `static int iteration_times`, I/iLQR.cpp:208).
+ *   - There is NO CPU fallback: every compute entry point fails with CILQR_ERR_NO_DEVICE when no
+ *     gfx950 device is usable.
+ */
+#ifndef CILQR_H_
+#define CILQR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CILQR_NX 4
+#define CILQR_NU 2
+#define CILQR_POLY_COEFFS 6   /* poly_order + 1, I/Parameters.cpp:7 */
+#define CILQR_MAX_HORIZON 128
+#define CILQR_ABI_VERSION 1
+
+/* Field-for-field POD mirror of class Parameters (I/Parameters.h:5-91) — only the fields the
+ * constructor initialises (I/Parameters.cpp:6-74) — plus the two constants iLQR::iLQR sets
+ * (lamb_factor, lamb_max; I/iLQR.cpp:17-18). */
+typedef struct cilqr_params {
+  /* planning parameters */
+  int32_t num_of_local_wpts;   /* 20  */
+  int32_t poly_order;          /* 5   */
+  /* iLQR parameters */
+  int32_t horizon;             /* 40  */
+  int32_t max_iterations;      /* 20  */
+  int32_t num_states;          /* 4   */
+  int32_t num_ctrls;           /* 2   */
+  double desired_speed;        /* 5.0 */
+  double timestep;             /* 0.1 */
+  double tolerance;            /* 1e-4 */
+  /* cost weights */
+  double w_acc, w_yawrate;     /* 1.0, 4.0 */
+  double w_pos, w_vel;         /* 0.65, 3.0 */
+  double w_obstacle, w_uncertainty; /* 1.0, 1.0 */
+  /* barrier q1/q2 */
+  double q1_acc, q2_acc;
+  double q1_yawrate, q2_yawrate;
+  double q1_front, q2_front;
+  double q1_rear, q2_rear;
+  double q1_uncertainty, q2_uncertainty;
+  /* limits */
+  double acc_max, acc_min;
+  double steer_angle_min, steer_angle_max;
+  /* ego vehicle */
+  double wheelbase, speed_max;
+  double steer_control_max, steer_control_min;
+  double throttle_control_max, throttle_control_min;
+  /* obstacle parameters */
+  double t_safe, s_safe_a, s_safe_b;
+  double ego_rad, ego_front, ego_rear;
+  double length, width;
+  double safe_length, safe_width;
+  /* iLQR::iLQR, I/iLQR.cpp:17-18 */
+  double lamb_factor, lamb_max;
+} cilqr_params;
+
+typedef enum cilqr_status {
+  CILQR_OK = 0,
+  CILQR_ERR_ARG = -1,        /* bad argument (null pointer, size out of the range given at create) */
+  CILQR_ERR_NO_DEVICE = -2,  /* no usable gfx950 device / HIP runtime error at create */
+  CILQR_ERR_HIP = -3,        /* HIP runtime error during a call */
+  CILQR_ERR_UNSUPPORTED = -4 /* parameter combination the kernels do not implement (e.g. num_states != 4) */
+} cilqr_status;
+
+/* Per-solve exit reason written to status_out (I/iLQR.cpp:211-239). */
+typedef enum cilqr_exit {
+  CILQR_EXIT_TOLERANCE = 0,   /* accepted step with |J_new - J_old| < tolerance  (:225-228) */
+  CILQR_EXIT_LAMBDA_MAX = 1,  /* rejected step drove lamb above lamb_max         (:232-236) */
+  CILQR_EXIT_MAX_ITER = 2,    /* loop ran max_iterations times                   (:211)     */
+  CILQR_EXIT_NUMERIC = 3      /* non-finite value met in the backward pass (reference: EigenSolver
+                                 failure → break, :214-215); X/U of the last accepted iterate */
+} cilqr_exit;
+
+/* Flags for cilqr_solve_batch*. */
+#define CILQR_FLAG_NONE 0u
+/* Execute the backward/forward passes of rejected iterations exactly as the reference loop does
+ * instead of stopping at the first rejection (results are identical). */
+#define CILQR_FLAG_FAITHFUL_ITERS 1u
+
+typedef struct cilqr_handle cilqr_handle;
+
+/* Geometry of a grid_map layer (G/grid_map_core/src/GridMap.cpp:45-62): float32, column-major
+ * rows×cols, cell (i,j) centre = pos + (len/2 - res/2) - res*(i,j)  (GridMapMath.cpp:114-127). */
+typedef struct cilqr_map_geom {
+  int32_t rows, cols;     /* size_(0), size_(1)  */
+  double res;             /* resolution_ */
+  double len_x, len_y;    /* length_  (= size*res after setGeometry) */
+  double pos_x, pos_y;    /* position_ (map centre in its parent frame) */
+} cilqr_map_geom;
+
+/* --- parameters ------------------------------------------------------------------------------- */
+void cilqr_params_default(cilqr_params* p);             /* I/Parameters.cpp:3-75 + I/iLQR.cpp:17-18 */
+int  cilqr_abi_version(void);
+const char* cilqr_last_error(void);
+
+/* Initial warm-start control sequence of a fresh planner (I/iLQR.cpp:9-15): row 0 = 0.5, row 1 = 0 for
+ * the first N/2 steps then 0.1.  Writes 2*N doubles. */
+int cilqr_default_control_seq(int N, double* U);
+
+/* --- host pre-step (stays on the host) -------------------------------------- */
+/* LocalPlanner::{closest_point_index,get_local_wpts,get_local_plan,get_local_plan_coeffs,polyfit}
+ * (I/LocalPlanner.cpp:25-117).  path: 2×P column-major.  Outputs: coeffs[poly_order+1]; ref_traj 2×n_out
+ * column-major (row 0 = waypoint x, row 1 = fitted y), n_out ≤ num_of_local_wpts written to *n_out. */
+int cilqr_local_plan(const cilqr_params* p, const double* path, int P, const double* ego_state,
+                     double* coeffs, double* ref_traj, int* n_out);
+
+/* --- solver ----------------------------------------------------------------------------------- */
+/* Sizes are upper bounds; device workspaces are allocated once here, never in solve. device = HIP
+ * ordinal. */
+int cilqr_create(const cilqr_params* p, int max_batch, int max_horizon, int max_obstacles, int device,
+                 cilqr_handle** out);
+int cilqr_destroy(cilqr_handle* h);
+
+/* Batched iLQR::get_optimal_control_seq (I/iLQR.cpp:201-245) — host buffers, synchronous.
+ *   x0        [B][4]            ego state (x, y, v, theta)
+ *   U         [B][2*N]  in/out  warm start in, U_result out (I/iLQR.cpp:222,244)
+ *   poly      [B][6]            poly_coeffs, ascending powers
+ *   xplan_fl  [B][2]            first and last element of x_local_plan (the only ones read,
+ *                               I/Constraints.cpp:31-33)
+ *   obs_pose  [B][M][4*N], obs_dim [B][M][2*N]   (ignored when M == 0)
+ *   obs_weight[B][M] or NULL    per-obstacle factor applied where the reference applies
+ *                               Parameters::w_obstacle (I/Constraints.cpp:184-185); NULL ⇒ p.w_obstacle
+ *   X_out     [B][4*(N+1)]      X_result
+ *   J_out     [B]               Constraints::get_J(X_result, U_result)
+ *   iters_out [B]               iteration_times of the reference loop (I/iLQR.cpp:212)
+ *   status_out[B]               cilqr_exit
+ * J_out / iters_out / status_out may be NULL. */
+int cilqr_solve_batch(cilqr_handle* h, int B, int N, int M,
+                      const double* x0, double* U, const double* poly, const double* xplan_fl,
+                      const double* obs_pose, const double* obs_dim, const double* obs_weight,
+                      double* X_out, double* J_out, int32_t* iters_out, int32_t* status_out,
+                      uint32_t flags);
+
+/* Same, with every pointer a DEVICE pointer on the handle's device and the work enqueued on `stream`
+ * (a hipStream_t passed as void*; NULL = the handle's own stream).  Asynchronous: returns after launch. */
+int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
+                             const double* x0, double* U, const double* poly, const double* xplan_fl,
+                             const double* obs_pose, const double* obs_dim, const double* obs_weight,
+                             double* X_out, double* J_out, int32_t* iters_out, int32_t* status_out,
+                             uint32_t flags);
+
+/* Local min-cost selection over a batch resident on the device (strict-< first-minimum tie-break, as in
+ * I/Constraints.cpp:50): writes {J_min, (double)index} to out_pair (device, 2 doubles).  The cross-GPU step
+ * is one all-gather of these 16-byte pairs (RCCL), done by the caller's communicator. */
+int cilqr_argmin_device(cilqr_handle* h, void* stream, int B, const double* J, double* out_pair);
+
+/* Blocks until everything enqueued on the handle's own stream has finished. */
+int cilqr_wait(cilqr_handle* h);
+
+/* --- costmap warp ----------------------------------------------------------------------------- */
+/* Rigid global→vehicle-frame warp (M/src/local_costmap.cpp:242-264): for every destination cell, centre C
+ * → g = Rot(theta)·C + (vx, vy) → nearest source cell (GridMap::atPosition, G/grid_map_core/src/GridMap.cpp:160-166);
+ * if bbox != NULL and bbox(cell) > 90 the destination takes the bbox value (:260-263).  Where the reference
+ * would throw std::out_of_range the destination is set to NaN and counted in *n_out_of_range (may be NULL).
+ * src: src_geom.rows×cols float32 column-major; dst/bbox: dst_geom.rows×cols float32 column-major. */
+int cilqr_warp_costmap(cilqr_handle* h, const float* src, const cilqr_map_geom* src_geom,
+                       float* dst, const cilqr_map_geom* dst_geom,
+                       double vx, double vy, double vtheta, const float* bbox, int64_t* n_out_of_range);
+/* Device-pointer form; n_out_of_range_dev is a device int64 counter (zeroed by the call) or NULL. */
+int cilqr_warp_costmap_device(cilqr_handle* h, void* stream, const float* src, const cilqr_map_geom* src_geom,
+                              float* dst, const cilqr_map_geom* dst_geom,
+                              double vx, double vy, double vtheta, const float* bbox,
+                              int64_t* n_out_of_range_dev);
+/* setGeometry(Length(lx,ly), res, Position(px,py)) size/length rule (G/grid_map_core/src/GridMap.cpp:45-62). */
+int cilqr_map_geom_set(cilqr_map_geom* g, double len_x, double len_y, double res, double pos_x, double pos_y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CILQR_H_ */

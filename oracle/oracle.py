@@ -1,0 +1,174 @@
+"""ctypes loader for the CPU oracle (oracle/build/liboracle.so) and the reference-built helpers
+(oracle/_ref/libref_*.so).  TEST INFRASTRUCTURE ONLY: import this from tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg — never from the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_ROOT = "/root/reference"
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+c_float_p = C.POINTER(C.c_float)
+
+
+class Params(C.Structure):
+    """Mirror of `cilqr_params` (include/cilqr.h)."""
+    _fields_ = [(n, C.c_int32) for n in
+                ("num_of_local_wpts", "poly_order", "horizon", "max_iterations", "num_states", "num_ctrls")] + \
+               [(n, C.c_double) for n in
+                ("desired_speed", "timestep", "tolerance", "w_acc", "w_yawrate", "w_pos", "w_vel", "w_obstacle",
+                 "w_uncertainty", "q1_acc", "q2_acc", "q1_yawrate", "q2_yawrate", "q1_front", "q2_front", "q1_rear",
+                 "q2_rear", "q1_uncertainty", "q2_uncertainty", "acc_max", "acc_min", "steer_angle_min",
+                 "steer_angle_max", "wheelbase", "speed_max", "steer_control_max", "steer_control_min",
+                 "throttle_control_max", "throttle_control_min", "t_safe", "s_safe_a", "s_safe_b", "ego_rad",
+                 "ego_front", "ego_rear", "length", "width", "safe_length", "safe_width", "lamb_factor", "lamb_max")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class MapGeom(C.Structure):
+    """Mirror of `cilqr_map_geom` (include/cilqr.h)."""
+    _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("res", C.c_double), ("len_x", C.c_double),
+                ("len_y", C.c_double), ("pos_x", C.c_double), ("pos_y", C.c_double)]
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(c_double_p)
+
+
+def _f64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def build(ref=True):
+    """Compile the restatement (always) and, when /root/reference exists, oracle/_ref."""
+    subprocess.run(["make", "-s", "-C", HERE], check=True)
+    if ref and os.path.isdir(REF_ROOT):
+        subprocess.run(["make", "-s", "-C", HERE, "ref"], check=True)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(HERE, "build", "liboracle.so")
+        if not os.path.exists(path):
+            build(ref=False)
+        L = C.CDLL(path)
+        L.oracle_get_J.restype = C.c_double
+        L.oracle_warp_costmap.restype = C.c_long
+        _lib = L
+    return _lib
+
+
+def ref_lib(name):
+    """Returns the CDLL for oracle/_ref/libref_<name>.so or None when it was not built."""
+    path = os.path.join(HERE, "_ref", "libref_%s.so" % name)
+    if not os.path.exists(path):
+        return None
+    L = C.CDLL(path)
+    if name == "gridmap":
+        L.ref_warp.restype = C.c_long
+    return L
+
+
+def default_params(horizon=None):
+    p = Params()
+    lib().oracle_params_default(C.byref(p))
+    if horizon is not None:
+        p.horizon = horizon
+    return p
+
+
+def default_control_seq(N):
+    U = np.zeros(2 * N)
+    lib().oracle_default_control_seq(N, _dp(U))
+    return U
+
+
+def solve(p, N, x0, U, coeffs, xf, xl, obs_pose=None, obs_dim=None, obs_weight=None):
+    """One reference-order solve.  Returns dict(U, X, J, iters, status, trace)."""
+    M = 0 if obs_pose is None else int(np.asarray(obs_pose).reshape(-1, 4 * N).shape[0])
+    x0 = _f64(x0)
+    U = _f64(U).copy()
+    coeffs = _f64(coeffs)
+    obs_pose = _f64(obs_pose)
+    obs_dim = _f64(obs_dim)
+    obs_weight = _f64(obs_weight)
+    X = np.zeros(4 * (N + 1))
+    J = C.c_double(0)
+    st = C.c_int(0)
+    trace = np.full(3 * p.max_iterations, np.nan)
+    it = lib().oracle_solve(C.byref(p), N, M, _dp(x0), _dp(U), _dp(coeffs), C.c_double(xf), C.c_double(xl),
+                            _dp(obs_pose), _dp(obs_dim), _dp(obs_weight), _dp(X), C.byref(J), C.byref(st), _dp(trace))
+    return dict(U=U, X=X, J=J.value, iters=it, status=st.value, trace=trace.reshape(-1, 3)[:it])
+
+
+def solve_batch(p, N, M, x0, U, poly, xplan_fl, obs_pose=None, obs_dim=None, obs_weight=None, threads=1):
+    B = int(np.asarray(x0).reshape(-1, 4).shape[0])
+    x0 = _f64(x0)
+    U = _f64(U).copy()
+    poly = _f64(poly)
+    xplan_fl = _f64(xplan_fl)
+    obs_pose = _f64(obs_pose)
+    obs_dim = _f64(obs_dim)
+    obs_weight = _f64(obs_weight)
+    X = np.zeros((B, 4 * (N + 1)))
+    J = np.zeros(B)
+    iters = np.zeros(B, dtype=np.int32)
+    status = np.zeros(B, dtype=np.int32)
+    lib().oracle_solve_batch(C.byref(p), B, N, M, _dp(x0), _dp(U), _dp(poly), _dp(xplan_fl), _dp(obs_pose),
+                             _dp(obs_dim), _dp(obs_weight), _dp(X), _dp(J), iters.ctypes.data_as(c_int_p),
+                             status.ctypes.data_as(c_int_p), int(threads))
+    return dict(U=U.reshape(B, 2 * N), X=X, J=J, iters=iters, status=status)
+
+
+def max_threads():
+    return int(lib().oracle_max_threads())
+
+
+def local_plan(p, path, ego):
+    path = _f64(path)
+    ego = _f64(ego)
+    P = path.size // 2
+    coeffs = np.zeros(p.poly_order + 1)
+    ref = np.zeros(2 * p.num_of_local_wpts)
+    n = lib().oracle_local_plan(C.byref(p), _dp(path), P, _dp(ego), _dp(coeffs), _dp(ref))
+    return coeffs, ref[:2 * n].reshape(n, 2)
+
+
+def polyfit(x, y, degree):
+    x = _f64(x)
+    y = _f64(y)
+    c = np.zeros(degree + 1)
+    lib().oracle_polyfit(_dp(x), _dp(y), int(x.size), int(degree), _dp(c))
+    return c
+
+
+def map_geom(len_x, len_y, res, pos_x, pos_y):
+    g = MapGeom()
+    lib().oracle_map_geom_set(C.byref(g), C.c_double(len_x), C.c_double(len_y), C.c_double(res), C.c_double(pos_x),
+                              C.c_double(pos_y))
+    return g
+
+
+def warp(src, sg, dg, vx, vy, vtheta, bbox=None, threads=1):
+    """src: (rows, cols) float32 in Fortran (column-major) order.  Returns (dst F-ordered, n_out_of_range)."""
+    src = np.asfortranarray(src, dtype=np.float32)
+    assert src.shape == (sg.rows, sg.cols)
+    dst = np.zeros((dg.rows, dg.cols), dtype=np.float32, order="F")
+    bb = None
+    if bbox is not None:
+        bbox = np.asfortranarray(bbox, dtype=np.float32)
+        bb = bbox.ctypes.data_as(c_float_p)
+    n = lib().oracle_warp_costmap(src.ctypes.data_as(c_float_p), C.byref(sg), dst.ctypes.data_as(c_float_p),
+                                  C.byref(dg), C.c_double(vx), C.c_double(vy), C.c_double(vtheta), bb, int(threads))
+    return dst, int(n)

@@ -1,0 +1,194 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against the CPU oracle on identical seeded inputs.
+
+Tolerances (stated here, used below):
+  * solver (fp64):  max|ΔU| ≤ 1e-6 is the BASELINE.json bar; TIGHT = 1e-9 is what this suite actually enforces on
+    scenes that are not decision knife-edges (observed ≈1e-12).  Iteration counts and exit reasons must be EQUAL.
+  * costmap warp (integer index math, float32 payload): bit-exact.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+BAR = 1e-6
+TIGHT = 1e-9
+
+
+@pytest.fixture(scope="module")
+def solver(cilqr):
+    p = cilqr.default_params()
+    s = cilqr.Solver(p, max_batch=2048, max_horizon=80, max_obstacles=64, device=0)
+    yield s
+    s.close()
+
+
+def _oracle_batch(O, N, sc, threads=16):
+    p = O.default_params(N)
+    return O.solve_batch(p, N, sc["M"], sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"],
+                         sc["obs_weight"], threads=min(threads, O.max_threads()))
+
+
+def _gpu_batch(solver, sc, flags=0):
+    return solver.solve_batch(sc["N"], sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"],
+                              sc["obs_weight"], flags=flags)
+
+
+def _compare(got, want, tol, what=""):
+    same_path = (got["iters"] == want["iters"]) & (got["status"] == want["status"])
+    du = np.max(np.abs(got["U"] - want["U"]), axis=1)
+    dx = np.max(np.abs(got["X"] - want["X"]), axis=1)
+    assert same_path.all(), "%s: %d solves took a different accept/reject path" % (what, int((~same_path).sum()))
+    assert du.max() <= tol, "%s: max|dU| = %g" % (what, du.max())
+    assert dx.max() <= 100 * tol, "%s: max|dX| = %g" % (what, dx.max())
+    assert np.allclose(got["J"], want["J"], rtol=1e-9, atol=1e-9), what
+    return du.max()
+
+
+@pytest.mark.parametrize("case", [c for c in load_golden("survey_known_answers.json")["cases"] if c["U0"] is not None],
+                         ids=lambda c: "N%d_M%d" % (c["N"], c["M"]))
+def test_known_answers_through_c_abi(cilqr, solver, case):
+    """The SURVEY §8(c) reference outputs, reproduced by the HIP path itself."""
+    from cilqr_amd import scenes
+    N, M = case["N"], case["M"]
+    sc = scenes.known_answer_scene(N, M, cilqr.default_params(N))
+    r = _gpu_batch(solver, sc)
+    assert r["iters"][0] == case["iterations"]
+    assert r["status"][0] == {"lambda_max": 1, "max_iter": 2}[case["exit"]]
+    assert np.max(np.abs(r["U"][0, :2] - np.array(case["U0"]))) < TIGHT
+    assert np.max(np.abs(r["X"][0, -4:] - np.array(case["XN"]))) < 1e-8
+
+
+def test_config2_batch_1024(cilqr, oracle, solver):
+    """BASELINE config 2 at full size: B=1024, N=50, M=4."""
+    from cilqr_amd import scenes
+    sc = scenes.make_c2(1024, cilqr.default_params(50))
+    got, want = _gpu_batch(solver, sc), _oracle_batch(oracle, 50, sc)
+    worst = _compare(got, want, TIGHT, "C2")
+    print("C2 B=1024 max|dU| = %.3e" % worst)
+    assert worst <= BAR
+
+
+def test_early_exit_equals_reference_loop(cilqr, solver):
+    """CILQR_FLAG_FAITHFUL_ITERS runs the rejected iterations' passes as the reference loop does: bit-identical results."""
+    from cilqr_amd import scenes
+    sc = scenes.make_c2(256, cilqr.default_params(50))
+    a, b = _gpu_batch(solver, sc), _gpu_batch(solver, sc, flags=cilqr.FLAG_FAITHFUL_ITERS)
+    for k in ("U", "X", "J", "iters", "status"):
+        assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("N,M,B,seed", [(30, 2, 128, 101), (80, 16, 128, 102), (50, 0, 64, 103), (1, 1, 8, 104), (64, 3, 32, 105),
+                                        (65, 3, 32, 106), (7, 5, 16, 107)])
+def test_other_shapes(cilqr, oracle, solver, N, M, B, seed):
+    """Config 1 / config 5 shapes, no obstacles, horizons around the wavefront width, tiny horizons."""
+    from cilqr_amd import scenes
+    sc = scenes.make_static(B, N, M, cilqr.default_params(N), seed)
+    _compare(_gpu_batch(solver, sc), _oracle_batch(oracle, N, sc), TIGHT, "N%d M%d" % (N, M))
+
+
+def test_config3_sampled_obstacles(cilqr, oracle, solver):
+    """Config 3 shape at reduced batch: 8 moving obstacles × 8 Gaussian samples, weight 1/8 (per-obstacle weights)."""
+    from cilqr_amd import scenes
+    sc = scenes.make_c3(48, cilqr.default_params(50), n_dyn=8, n_samples=8)
+    _compare(_gpu_batch(solver, sc), _oracle_batch(oracle, 50, sc), TIGHT, "C3")
+
+
+def test_warm_start_second_tick(cilqr, oracle, solver):
+    """control_seq persists un-shifted across run_step calls (I/iLQR.cpp:253): feed U_result back in."""
+    from cilqr_amd import scenes
+    sc = scenes.make_c2(64, cilqr.default_params(50))
+    g1, o1 = _gpu_batch(solver, sc), _oracle_batch(oracle, 50, sc)
+    sc_g, sc_o = dict(sc, U=g1["U"]), dict(sc, U=o1["U"])
+    _compare(_gpu_batch(solver, sc_g), _oracle_batch(oracle, 50, sc_o), 1e-8, "tick 2")
+
+
+def test_committed_regression_vectors(cilqr, solver):
+    for c in load_golden("oracle_solves.json")["cases"]:
+        N, M, B = c["N"], c["M"], c["B"]
+        inp = {k: (None if v is None else np.array(v)) for k, v in c["inputs"].items()}
+        got = solver.solve_batch(N, inp["x0"], inp["U"], inp["poly"], inp["xplan_fl"], inp["obs_pose"], inp["obs_dim"])
+        want = dict(U=np.array(c["U"]), X=np.array(c["X"]), J=np.array(c["J"]), iters=np.array(c["iters"]), status=np.array(c["status"]))
+        _compare(got, want, TIGHT, c["name"])
+
+
+def test_empty_batch_and_bounds(cilqr, solver):
+    import ctypes as C
+    L = cilqr.lib()
+    z = np.zeros(8)
+    zp = z.ctypes.data_as(C.POINTER(C.c_double))
+    assert L.cilqr_solve_batch(solver._h, 0, 50, 0, zp, zp, zp, zp, None, None, None, zp, None, None, None, 0) == 0
+    assert L.cilqr_solve_batch(solver._h, 4096, 50, 0, zp, zp, zp, zp, None, None, None, zp, None, None, None, 0) == -1
+    assert L.cilqr_solve_batch(solver._h, 1, 50, 2, zp, zp, zp, zp, None, None, None, zp, None, None, None, 0) == -1
+
+
+def test_nonfinite_input_is_contained(cilqr, solver):
+    """A NaN start state must not hang or poison neighbours; the solve reports it through status / NaN outputs."""
+    from cilqr_amd import scenes
+    sc = scenes.make_c2(8, cilqr.default_params(50))
+    clean = _gpu_batch(solver, sc)
+    sc["x0"] = sc["x0"].copy()
+    sc["x0"][3, 1] = np.nan
+    r = _gpu_batch(solver, sc)
+    keep = np.arange(8) != 3
+    assert np.array_equal(r["U"][keep], clean["U"][keep])
+    assert r["iters"][3] >= 1
+
+
+# ------------------------------------------------------------------------------------------------ argmin
+def test_argmin_device(cilqr, solver):
+    import torch
+    J = torch.rand(5000, dtype=torch.float64, device="cuda")
+    J[1234] = -1.0
+    J[4321] = -1.0  # tie → lowest index
+    J[7] = float("nan")
+    out = torch.zeros(2, dtype=torch.float64, device="cuda")
+    solver.argmin_device(torch.cuda.current_stream().cuda_stream, 5000, J.data_ptr(), out.data_ptr())
+    torch.cuda.synchronize()
+    assert out.tolist() == [-1.0, 1234.0]
+
+
+# ------------------------------------------------------------------------------------------------ warp
+def test_warp_golden_cases(cilqr, solver):
+    for k, c in enumerate(load_golden("ref_gridmap.json")["warp"]):
+        sg, dg = cilqr.map_geom(*c["src_geom"]), cilqr.map_geom(*c["dst_geom"])
+        src = np.array([np.nan if v is None else v for v in c["src"]], dtype=np.float32).reshape(c["src_shape"], order="F")
+        bbox = None if c["bbox"] is None else np.array(c["bbox"], dtype=np.float32).reshape(c["dst_shape"], order="F")
+        want = np.array([np.nan if v is None else v for v in c["dst"]], dtype=np.float32).reshape(c["dst_shape"], order="F")
+        got, oob = solver.warp_costmap(src, sg, dg, *c["pose"], bbox=bbox)
+        assert oob == c["n_out_of_range"], k
+        assert np.array_equal(got, want, equal_nan=True), k
+
+
+def test_warp_config4_frames(cilqr, oracle, solver):
+    """BASELINE config 4 at full size (1024² → 1024²): a sample of the 300-frame pose stream + the deliberately
+    out-of-range frame, bit-exact against the oracle; plus the size-independent round-trip property below."""
+    from cilqr_amd import scenes
+    c4 = scenes.make_c4()
+    sg, dg = cilqr.map_geom(*c4["src_geom"]), cilqr.map_geom(*c4["dst_geom"])
+    osg, odg = oracle.map_geom(*c4["src_geom"]), oracle.map_geom(*c4["dst_geom"])
+    poses = [tuple(c4["poses"][k]) for k in (0, 37, 75, 150, 299)] + [(80.0, 80.0, 0.3)]
+    for pose in poses:
+        got, oob = solver.warp_costmap(c4["src"], sg, dg, *pose)
+        want, woob = oracle.warp(c4["src"], osg, odg, *pose, threads=16)
+        assert oob == woob
+        assert np.array_equal(got, want, equal_nan=True)
+    assert oob > 0  # the last frame leaves the source map
+
+
+def test_warp_identity_and_bbox(cilqr, solver):
+    """Size-independent properties: an identity pose with equal geometry copies the map; a bbox layer > 90 overrides."""
+    rng = np.random.default_rng(9)
+    g = cilqr.map_geom(204.8, 204.8, 0.2, 5.0, -3.0)
+    src = np.asfortranarray(rng.integers(0, 101, (g.rows, g.cols)).astype(np.float32))
+    # the destination map's position is expressed in the vehicle frame; with V = 0 and theta = 0 frames coincide
+    got, oob = solver.warp_costmap(src, g, g, 0.0, 0.0, 0.0)
+    assert oob == 0 and np.array_equal(got, src)
+    bbox = np.zeros_like(src)
+    bbox[100:200, 300:400] = 100.0
+    bbox[0, 0] = 90.0  # not > 90: no override
+    got, _ = solver.warp_costmap(src, g, g, 0.0, 0.0, 0.0, bbox=bbox)
+    assert np.all(got[100:200, 300:400] == 100.0) and got[0, 0] == src[0, 0]
+    mask = bbox <= 90
+    assert np.array_equal(got[mask], src[mask])

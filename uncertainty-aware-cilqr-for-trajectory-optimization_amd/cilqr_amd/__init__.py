@@ -1,0 +1,202 @@
+"""cilqr_amd — thin Python host binding (ctypes) over the C-ABI of include/cilqr.h.
+
+The product is `lib/libcilqr_hip.so` (hand-written HIP for gfx950 + the C-ABI); this module only loads it and
+marshals numpy / torch buffers into plain pointers.  There is no CPU fallback here or in the library: if the
+shared object is missing or no gfx950 device is usable, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(PKG_ROOT, "lib", "libcilqr_hip.so")
+
+NX, NU, POLY = 4, 2, 6
+FLAG_FAITHFUL_ITERS = 1
+EXIT_TOLERANCE, EXIT_LAMBDA_MAX, EXIT_MAX_ITER, EXIT_NUMERIC = 0, 1, 2, 3
+
+# every symbol include/cilqr.h declares
+ABI_SYMBOLS = (
+    "cilqr_params_default", "cilqr_abi_version", "cilqr_last_error", "cilqr_default_control_seq",
+    "cilqr_local_plan", "cilqr_create", "cilqr_destroy", "cilqr_solve_batch", "cilqr_solve_batch_device",
+    "cilqr_argmin_device", "cilqr_wait", "cilqr_warp_costmap", "cilqr_warp_costmap_device", "cilqr_map_geom_set",
+)
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_fp = C.POINTER(C.c_float)
+
+
+class Params(C.Structure):
+    """`cilqr_params` — POD mirror of the reference's Parameters (I/Parameters.h:5-91)."""
+    _fields_ = [(n, C.c_int32) for n in
+                ("num_of_local_wpts", "poly_order", "horizon", "max_iterations", "num_states", "num_ctrls")] + \
+               [(n, C.c_double) for n in
+                ("desired_speed", "timestep", "tolerance", "w_acc", "w_yawrate", "w_pos", "w_vel", "w_obstacle",
+                 "w_uncertainty", "q1_acc", "q2_acc", "q1_yawrate", "q2_yawrate", "q1_front", "q2_front", "q1_rear",
+                 "q2_rear", "q1_uncertainty", "q2_uncertainty", "acc_max", "acc_min", "steer_angle_min",
+                 "steer_angle_max", "wheelbase", "speed_max", "steer_control_max", "steer_control_min",
+                 "throttle_control_max", "throttle_control_min", "t_safe", "s_safe_a", "s_safe_b", "ego_rad",
+                 "ego_front", "ego_rear", "length", "width", "safe_length", "safe_width", "lamb_factor", "lamb_max")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class MapGeom(C.Structure):
+    """`cilqr_map_geom` — geometry of a grid_map layer."""
+    _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("res", C.c_double), ("len_x", C.c_double),
+                ("len_y", C.c_double), ("pos_x", C.c_double), ("pos_y", C.c_double)]
+
+
+class CilqrError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Loads lib/libcilqr_hip.so (raises if it has not been built: there is no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CilqrError("%s not built — run __graft_entry__.build() (hipcc --offload-arch=gfx950)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.cilqr_last_error.restype = C.c_char_p
+        for name in ABI_SYMBOLS:
+            getattr(L, name)  # AttributeError if a declared symbol is not exported
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise CilqrError("cilqr error %d: %s" % (rc, lib().cilqr_last_error().decode()))
+
+
+def default_params(horizon=None):
+    p = Params()
+    lib().cilqr_params_default(C.byref(p))
+    if horizon is not None:
+        p.horizon = horizon
+    return p
+
+
+def default_control_seq(N):
+    U = np.zeros(2 * N)
+    _check(lib().cilqr_default_control_seq(int(N), U.ctypes.data_as(_dp)))
+    return U
+
+
+def local_plan(p, path, ego):
+    """LocalPlanner pre-step.  path: (P, 2) waypoints.  Returns (coeffs[6], ref_traj (n, 2))."""
+    path = np.ascontiguousarray(path, dtype=np.float64)
+    ego = np.ascontiguousarray(ego, dtype=np.float64)
+    coeffs = np.zeros(p.poly_order + 1)
+    ref = np.zeros(2 * p.num_of_local_wpts)
+    n = C.c_int(0)
+    _check(lib().cilqr_local_plan(C.byref(p), path.ctypes.data_as(_dp), int(path.size // 2), ego.ctypes.data_as(_dp),
+                                  coeffs.ctypes.data_as(_dp), ref.ctypes.data_as(_dp), C.byref(n)))
+    return coeffs, ref[:2 * n.value].reshape(n.value, 2)
+
+
+def map_geom(len_x, len_y, res, pos_x, pos_y):
+    g = MapGeom()
+    _check(lib().cilqr_map_geom_set(C.byref(g), C.c_double(len_x), C.c_double(len_y), C.c_double(res),
+                                    C.c_double(pos_x), C.c_double(pos_y)))
+    return g
+
+
+def _np64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a, t=_dp):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+def _vp(ptr):
+    return C.c_void_p(int(ptr)) if ptr else None
+
+
+class Solver:
+    """One handle = one device = one host thread at a time (mirrors one reference `iLQR` object per batch slot)."""
+
+    def __init__(self, params=None, max_batch=1024, max_horizon=50, max_obstacles=4, device=0):
+        self.params = params if params is not None else default_params()
+        self.max_batch, self.max_horizon, self.max_obstacles, self.device = max_batch, max_horizon, max_obstacles, device
+        self._h = C.c_void_p()
+        _check(lib().cilqr_create(C.byref(self.params), int(max_batch), int(max_horizon), int(max_obstacles),
+                                  int(device), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().cilqr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-buffer entry point (synchronous) ----
+    def solve_batch(self, N, x0, U, poly, xplan_fl, obs_pose=None, obs_dim=None, obs_weight=None, flags=0):
+        x0 = _np64(x0).reshape(-1, 4)
+        B = x0.shape[0]
+        U = _np64(U).reshape(B, 2 * N).copy()
+        poly = _np64(poly).reshape(B, POLY)
+        xplan_fl = _np64(xplan_fl).reshape(B, 2)
+        M = 0
+        if obs_pose is not None:
+            obs_pose = _np64(obs_pose).reshape(B, -1, 4 * N)
+            M = obs_pose.shape[1]
+            obs_dim = _np64(obs_dim).reshape(B, M, 2 * N)
+            if obs_weight is not None:
+                obs_weight = _np64(obs_weight).reshape(B, M)
+        X = np.zeros((B, 4 * (N + 1)))
+        J = np.zeros(B)
+        iters = np.zeros(B, dtype=np.int32)
+        status = np.zeros(B, dtype=np.int32)
+        _check(lib().cilqr_solve_batch(self._h, B, int(N), int(M), _p(x0), _p(U), _p(poly), _p(xplan_fl), _p(obs_pose),
+                                       _p(obs_dim), _p(obs_weight), _p(X), _p(J), _p(iters, _ip), _p(status, _ip),
+                                       C.c_uint32(flags)))
+        return dict(U=U, X=X, J=J, iters=iters, status=status)
+
+    # ---- device-pointer entry point (asynchronous on `stream`) ----
+    def solve_batch_device(self, stream, B, N, M, x0, U, poly, xplan_fl, obs_pose, obs_dim, obs_weight, X_out, J_out,
+                           iters_out, status_out, flags=0):
+        """All pointer arguments are integer device addresses (e.g. torch.Tensor.data_ptr()); 0/None = NULL."""
+        _check(lib().cilqr_solve_batch_device(self._h, _vp(stream), int(B), int(N), int(M), _vp(x0), _vp(U), _vp(poly),
+                                              _vp(xplan_fl), _vp(obs_pose), _vp(obs_dim), _vp(obs_weight), _vp(X_out),
+                                              _vp(J_out), _vp(iters_out), _vp(status_out), C.c_uint32(flags)))
+
+    def argmin_device(self, stream, B, J, out_pair):
+        _check(lib().cilqr_argmin_device(self._h, _vp(stream), int(B), _vp(J), _vp(out_pair)))
+
+    def wait(self):
+        _check(lib().cilqr_wait(self._h))
+
+    # ---- costmap warp ----
+    def warp_costmap(self, src, src_geom, dst_geom, vx, vy, vtheta, bbox=None):
+        """src: (rows, cols) float32 (any order; converted to column-major).  Returns (dst F-ordered, n_out_of_range)."""
+        src = np.asfortranarray(src, dtype=np.float32)
+        assert src.shape == (src_geom.rows, src_geom.cols)
+        dst = np.zeros((dst_geom.rows, dst_geom.cols), dtype=np.float32, order="F")
+        bb = None
+        if bbox is not None:
+            bbox = np.asfortranarray(bbox, dtype=np.float32)
+            assert bbox.shape == dst.shape
+            bb = bbox.ctypes.data_as(_fp)
+        n = C.c_int64(0)
+        _check(lib().cilqr_warp_costmap(self._h, src.ctypes.data_as(_fp), C.byref(src_geom), dst.ctypes.data_as(_fp),
+                                        C.byref(dst_geom), C.c_double(vx), C.c_double(vy), C.c_double(vtheta), bb,
+                                        C.byref(n)))
+        return dst, int(n.value)
+
+    def warp_costmap_device(self, stream, src, src_geom, dst, dst_geom, vx, vy, vtheta, bbox=0, n_oob=0):
+        _check(lib().cilqr_warp_costmap_device(self._h, _vp(stream), _vp(src), C.byref(src_geom), _vp(dst),
+                                               C.byref(dst_geom), C.c_double(vx), C.c_double(vy), C.c_double(vtheta),
+                                               _vp(bbox), _vp(n_oob)))

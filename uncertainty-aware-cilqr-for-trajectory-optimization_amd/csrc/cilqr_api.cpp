@@ -1,0 +1,336 @@
+// cilqr_api.cpp — the C-ABI of include/cilqr.h over the HIP kernels.  No CPU fallback: compute entry points
+// fail with CILQR_ERR_NO_DEVICE / CILQR_ERR_HIP when the device path is unavailable.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+
+#include "cilqr_internal.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) return fail(CILQR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+}  // namespace
+
+struct cilqr_handle {
+  cilqr_params params;
+  cilqr::KParams kp;
+  int device;
+  int max_batch, max_horizon, max_obstacles;
+  hipStream_t stream;
+  // device staging for the host-pointer entry points
+  double *d_x0, *d_U, *d_poly, *d_xplan, *d_obs_pose, *d_obs_dim, *d_obs_w, *d_X, *d_J;
+  int32_t *d_iters, *d_status;
+  // workspace
+  double* d_obs_tab;
+  double* d_pair;
+  // warp staging (grown on demand by the host-pointer warp entry point only)
+  float *d_src, *d_dst, *d_bbox;
+  size_t src_cap, dst_cap, bbox_cap;
+  unsigned long long* d_oob;
+};
+
+namespace {
+
+void derive(const cilqr_params& p, cilqr::KParams& k) {
+  k.dt = p.timestep;
+  k.desired_speed = p.desired_speed;
+  k.tolerance = p.tolerance;
+  k.w_acc = p.w_acc; k.w_yawrate = p.w_yawrate; k.w_pos = p.w_pos; k.w_vel = p.w_vel; k.w_obstacle = p.w_obstacle;
+  k.q1_acc = p.q1_acc; k.q2_acc = p.q2_acc; k.q1_yawrate = p.q1_yawrate; k.q2_yawrate = p.q2_yawrate;
+  k.q1_front = p.q1_front; k.q2_front = p.q2_front; k.q1_rear = p.q1_rear; k.q2_rear = p.q2_rear;
+  k.acc_max = p.acc_max; k.acc_min = p.acc_min;
+  k.tan_steer_max = tan(p.steer_angle_max);
+  k.tan_steer_min = tan(p.steer_angle_min);
+  k.wheelbase = p.wheelbase; k.speed_max = p.speed_max;
+  k.t_safe = p.t_safe; k.s_safe_a = p.s_safe_a; k.s_safe_b = p.s_safe_b;
+  k.ego_rad = p.ego_rad; k.ego_front = p.ego_front; k.ego_rear = p.ego_rear;
+  k.lamb_factor = p.lamb_factor; k.lamb_max = p.lamb_max;
+  k.max_iterations = p.max_iterations;
+  k.n_samples = p.num_of_local_wpts * 10;
+}
+
+int check_sizes(const cilqr_handle* h, int B, int N, int M) {
+  if (!h) return fail(CILQR_ERR_ARG, "null handle");
+  if (B < 0 || B > h->max_batch) return fail(CILQR_ERR_ARG, "B=%d outside [0,%d]", B, h->max_batch);
+  if (N < 1 || N > h->max_horizon) return fail(CILQR_ERR_ARG, "N=%d outside [1,%d]", N, h->max_horizon);
+  if (M < 0 || M > h->max_obstacles) return fail(CILQR_ERR_ARG, "M=%d outside [0,%d]", M, h->max_obstacles);
+  return CILQR_OK;
+}
+
+template <typename T>
+hipError_t dmalloc(T** p, size_t n) {
+  *p = nullptr;
+  if (n == 0) return hipSuccess;
+  return hipMalloc((void**)p, n * sizeof(T));
+}
+
+}  // namespace
+
+extern "C" {
+
+int cilqr_abi_version(void) { return CILQR_ABI_VERSION; }
+
+const char* cilqr_last_error(void) { return g_last_error.c_str(); }
+
+void cilqr_params_default(cilqr_params* p) {
+  if (!p) return;
+  memset(p, 0, sizeof(*p));
+  // planning / iLQR (I/Parameters.cpp:6-16)
+  p->num_of_local_wpts = 20; p->poly_order = 5; p->desired_speed = 5.0;
+  p->timestep = 0.1; p->horizon = 40; p->tolerance = 1e-4; p->max_iterations = 20;
+  p->num_states = 4; p->num_ctrls = 2;
+  // weights (:19-26)
+  p->w_acc = 1.0; p->w_yawrate = 4.0; p->w_pos = 0.65; p->w_vel = 3.0; p->w_obstacle = 1.0; p->w_uncertainty = 1.0;
+  // barrier constants (:29-42)
+  p->q1_acc = 1.0; p->q2_acc = 1.0; p->q1_yawrate = 1.0; p->q2_yawrate = 1.0;
+  p->q1_front = 2.75; p->q2_front = 2.75; p->q1_rear = 2.5; p->q2_rear = 2.5;
+  p->q1_uncertainty = 2.5; p->q2_uncertainty = 2.5;
+  // limits and vehicle (:45-60)
+  p->acc_max = 2.0; p->acc_min = -5.5; p->steer_angle_min = -0.75; p->steer_angle_max = 0.75;
+  p->wheelbase = 2.94; p->speed_max = 30.0;
+  p->steer_control_max = 1.0; p->steer_control_min = -1.0;
+  p->throttle_control_max = 1.0; p->throttle_control_min = -1.0;
+  // obstacle model (:63-74)
+  p->t_safe = 0.1; p->s_safe_a = 0; p->s_safe_b = 0; p->ego_rad = 1.35;
+  p->ego_front = 1.47 + 0.925; p->ego_rear = 1.47 + 0.925;
+  p->length = 4.79; p->width = 2.16; p->safe_length = 0.0; p->safe_width = 0.0;
+  // I/iLQR.cpp:17-18
+  p->lamb_factor = 10; p->lamb_max = 10000;
+}
+
+int cilqr_default_control_seq(int N, double* U) {
+  if (N < 1 || !U) return fail(CILQR_ERR_ARG, "cilqr_default_control_seq: bad argument");
+  const int num_zeros = N / 2;  // I/iLQR.cpp:12
+  for (int i = 0; i < N; ++i) {
+    U[2 * i] = 0.5;
+    U[2 * i + 1] = i < num_zeros ? 0.0 : 0.1;
+  }
+  return CILQR_OK;
+}
+
+int cilqr_create(const cilqr_params* p, int max_batch, int max_horizon, int max_obstacles, int device,
+                 cilqr_handle** out) {
+  if (!p || !out) return fail(CILQR_ERR_ARG, "cilqr_create: null argument");
+  *out = nullptr;
+  if (max_batch < 1 || max_horizon < 1 || max_horizon > CILQR_MAX_HORIZON || max_obstacles < 0)
+    return fail(CILQR_ERR_ARG, "cilqr_create: sizes out of range (max_horizon ≤ %d)", CILQR_MAX_HORIZON);
+  if (p->num_states != CILQR_NX || p->num_ctrls != CILQR_NU || p->poly_order + 1 != CILQR_POLY_COEFFS)
+    return fail(CILQR_ERR_UNSUPPORTED, "only num_states=4, num_ctrls=2, poly_order=5 are implemented (reference model, I/Model.cpp)");
+  if (p->num_of_local_wpts < 1 || p->num_of_local_wpts > 100 || p->max_iterations < 1)
+    return fail(CILQR_ERR_ARG, "cilqr_create: num_of_local_wpts / max_iterations out of range");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(CILQR_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  if (device < 0 || device >= count) return fail(CILQR_ERR_ARG, "device %d not in [0,%d)", device, count);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(CILQR_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(CILQR_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+  if (hipSetDevice(device) != hipSuccess) return fail(CILQR_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+
+  cilqr_handle* h = new (std::nothrow) cilqr_handle();
+  if (!h) return fail(CILQR_ERR_ARG, "out of host memory");
+  memset(h, 0, sizeof(*h));
+  h->params = *p;
+  derive(*p, h->kp);
+  h->device = device;
+  h->max_batch = max_batch; h->max_horizon = max_horizon; h->max_obstacles = max_obstacles;
+  const size_t B = max_batch, N = max_horizon, M = max_obstacles;
+  hipError_t err = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (err == hipSuccess) err = dmalloc(&h->d_x0, B * 4);
+  if (err == hipSuccess) err = dmalloc(&h->d_U, B * 2 * N);
+  if (err == hipSuccess) err = dmalloc(&h->d_poly, B * CILQR_POLY_COEFFS);
+  if (err == hipSuccess) err = dmalloc(&h->d_xplan, B * 2);
+  if (err == hipSuccess) err = dmalloc(&h->d_obs_pose, B * M * N * 4);
+  if (err == hipSuccess) err = dmalloc(&h->d_obs_dim, B * M * N * 2);
+  if (err == hipSuccess) err = dmalloc(&h->d_obs_w, B * M);
+  if (err == hipSuccess) err = dmalloc(&h->d_X, B * 4 * (N + 1));
+  if (err == hipSuccess) err = dmalloc(&h->d_J, B);
+  if (err == hipSuccess) err = dmalloc(&h->d_iters, B);
+  if (err == hipSuccess) err = dmalloc(&h->d_status, B);
+  if (err == hipSuccess) err = dmalloc(&h->d_obs_tab, B * M * N * 6);
+  if (err == hipSuccess) err = dmalloc(&h->d_pair, (size_t)2);
+  if (err == hipSuccess) err = dmalloc(&h->d_oob, (size_t)1);
+  if (err != hipSuccess) {
+    int rc = fail(CILQR_ERR_HIP, "cilqr_create: device allocation failed: %s", hipGetErrorString(err));
+    cilqr_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return CILQR_OK;
+}
+
+int cilqr_destroy(cilqr_handle* h) {
+  if (!h) return CILQR_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  void* ptrs[] = {h->d_x0, h->d_U, h->d_poly, h->d_xplan, h->d_obs_pose, h->d_obs_dim, h->d_obs_w, h->d_X, h->d_J,
+                  h->d_iters, h->d_status, h->d_obs_tab, h->d_pair, h->d_src, h->d_dst, h->d_bbox, h->d_oob};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return CILQR_OK;
+}
+
+int cilqr_wait(cilqr_handle* h) {
+  if (!h) return fail(CILQR_ERR_ARG, "null handle");
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CILQR_OK;
+}
+
+int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M, const double* x0, double* U,
+                             const double* poly, const double* xplan_fl, const double* obs_pose, const double* obs_dim,
+                             const double* obs_weight, double* X_out, double* J_out, int32_t* iters_out,
+                             int32_t* status_out, uint32_t flags) {
+  int rc = check_sizes(h, B, N, M);
+  if (rc) return rc;
+  if (B == 0) return CILQR_OK;
+  if (!x0 || !U || !poly || !xplan_fl || !X_out) return fail(CILQR_ERR_ARG, "cilqr_solve_batch: null required pointer");
+  if (M > 0 && (!obs_pose || !obs_dim)) return fail(CILQR_ERR_ARG, "cilqr_solve_batch: M > 0 but obstacle tables are null");
+  cilqr::SolveArgs a;
+  a.x0 = x0; a.U = U; a.poly = poly; a.xplan_fl = xplan_fl;
+  a.obs_pose = obs_pose; a.obs_dim = obs_dim; a.obs_weight = M > 0 ? obs_weight : nullptr;
+  a.X_out = X_out; a.J_out = J_out; a.iters_out = iters_out; a.status_out = status_out;
+  a.obs_tab = h->d_obs_tab;
+  a.B = B; a.N = N; a.M = M; a.flags = flags;
+  a.kp = h->kp;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(cilqr::launch_solve(a, stream ? (hipStream_t)stream : h->stream));
+  return CILQR_OK;
+}
+
+int cilqr_solve_batch(cilqr_handle* h, int B, int N, int M, const double* x0, double* U, const double* poly,
+                      const double* xplan_fl, const double* obs_pose, const double* obs_dim, const double* obs_weight,
+                      double* X_out, double* J_out, int32_t* iters_out, int32_t* status_out, uint32_t flags) {
+  int rc = check_sizes(h, B, N, M);
+  if (rc) return rc;
+  if (B == 0) return CILQR_OK;
+  if (!x0 || !U || !poly || !xplan_fl || !X_out) return fail(CILQR_ERR_ARG, "cilqr_solve_batch: null required pointer");
+  if (M > 0 && (!obs_pose || !obs_dim)) return fail(CILQR_ERR_ARG, "cilqr_solve_batch: M > 0 but obstacle tables are null");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  const size_t b = B, n = N, m = M;
+  HIP_TRY(hipMemcpyAsync(h->d_x0, x0, b * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->d_U, U, b * 2 * n * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->d_poly, poly, b * CILQR_POLY_COEFFS * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->d_xplan, xplan_fl, b * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+  if (M > 0) {
+    HIP_TRY(hipMemcpyAsync(h->d_obs_pose, obs_pose, b * m * n * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->d_obs_dim, obs_dim, b * m * n * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+    if (obs_weight) HIP_TRY(hipMemcpyAsync(h->d_obs_w, obs_weight, b * m * sizeof(double), hipMemcpyHostToDevice, s));
+  }
+  rc = cilqr_solve_batch_device(h, s, B, N, M, h->d_x0, h->d_U, h->d_poly, h->d_xplan, h->d_obs_pose, h->d_obs_dim,
+                                (M > 0 && obs_weight) ? h->d_obs_w : nullptr, h->d_X, h->d_J, h->d_iters, h->d_status, flags);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(U, h->d_U, b * 2 * n * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(X_out, h->d_X, b * 4 * (n + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (J_out) HIP_TRY(hipMemcpyAsync(J_out, h->d_J, b * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (iters_out) HIP_TRY(hipMemcpyAsync(iters_out, h->d_iters, b * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  if (status_out) HIP_TRY(hipMemcpyAsync(status_out, h->d_status, b * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return CILQR_OK;
+}
+
+int cilqr_argmin_device(cilqr_handle* h, void* stream, int B, const double* J, double* out_pair) {
+  if (!h || !J || !out_pair || B < 1) return fail(CILQR_ERR_ARG, "cilqr_argmin_device: bad argument");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(cilqr::launch_argmin(J, B, out_pair, nullptr, stream ? (hipStream_t)stream : h->stream));
+  return CILQR_OK;
+}
+
+int cilqr_map_geom_set(cilqr_map_geom* g, double len_x, double len_y, double res, double pos_x, double pos_y) {
+  if (!g || !(len_x > 0.0) || !(len_y > 0.0) || !(res > 0.0)) return fail(CILQR_ERR_ARG, "cilqr_map_geom_set: bad argument");
+  // GridMap::setGeometry (G/grid_map_core/src/GridMap.cpp:45-62)
+  g->rows = (int)round(len_x / res);
+  g->cols = (int)round(len_y / res);
+  g->res = res;
+  g->len_x = (double)g->rows * res;
+  g->len_y = (double)g->cols * res;
+  g->pos_x = pos_x;
+  g->pos_y = pos_y;
+  return CILQR_OK;
+}
+
+int cilqr_warp_costmap_device(cilqr_handle* h, void* stream, const float* src, const cilqr_map_geom* sg, float* dst,
+                              const cilqr_map_geom* dg, double vx, double vy, double vtheta, const float* bbox,
+                              int64_t* n_oob_dev) {
+  if (!h || !src || !sg || !dst || !dg) return fail(CILQR_ERR_ARG, "cilqr_warp_costmap: null argument");
+  if (sg->rows < 1 || sg->cols < 1 || dg->rows < 1 || dg->cols < 1 || !(sg->res > 0.0) || !(dg->res > 0.0))
+    return fail(CILQR_ERR_ARG, "cilqr_warp_costmap: bad geometry");
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  HIP_TRY(hipSetDevice(h->device));
+  cilqr::WarpArgs a;
+  a.src = src; a.dst = dst; a.bbox = bbox;
+  a.n_oob = (unsigned long long*)n_oob_dev;
+  a.sg = *sg; a.dg = *dg;
+  a.vx = vx; a.vy = vy;
+  a.sin_t = sin(vtheta);  // host libm, as the reference (M/src/local_costmap.cpp:201-202)
+  a.cos_t = cos(vtheta);
+  if (n_oob_dev) HIP_TRY(hipMemsetAsync(n_oob_dev, 0, sizeof(int64_t), s));
+  HIP_TRY(cilqr::launch_warp(a, s));
+  return CILQR_OK;
+}
+
+int cilqr_warp_costmap(cilqr_handle* h, const float* src, const cilqr_map_geom* sg, float* dst, const cilqr_map_geom* dg,
+                       double vx, double vy, double vtheta, const float* bbox, int64_t* n_out_of_range) {
+  if (!h || !src || !sg || !dst || !dg) return fail(CILQR_ERR_ARG, "cilqr_warp_costmap: null argument");
+  if (sg->rows < 1 || sg->cols < 1 || dg->rows < 1 || dg->cols < 1) return fail(CILQR_ERR_ARG, "cilqr_warp_costmap: bad geometry");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t ns = (size_t)sg->rows * sg->cols, nd = (size_t)dg->rows * dg->cols;
+  if (ns > h->src_cap) {
+    if (h->d_src) HIP_TRY(hipFree(h->d_src));
+    h->d_src = nullptr; h->src_cap = 0;
+    HIP_TRY(dmalloc(&h->d_src, ns));
+    h->src_cap = ns;
+  }
+  if (nd > h->dst_cap) {
+    if (h->d_dst) HIP_TRY(hipFree(h->d_dst));
+    h->d_dst = nullptr; h->dst_cap = 0;
+    HIP_TRY(dmalloc(&h->d_dst, nd));
+    h->dst_cap = nd;
+  }
+  if (bbox && nd > h->bbox_cap) {
+    if (h->d_bbox) HIP_TRY(hipFree(h->d_bbox));
+    h->d_bbox = nullptr; h->bbox_cap = 0;
+    HIP_TRY(dmalloc(&h->d_bbox, nd));
+    h->bbox_cap = nd;
+  }
+  hipStream_t s = h->stream;
+  HIP_TRY(hipMemcpyAsync(h->d_src, src, ns * sizeof(float), hipMemcpyHostToDevice, s));
+  if (bbox) HIP_TRY(hipMemcpyAsync(h->d_bbox, bbox, nd * sizeof(float), hipMemcpyHostToDevice, s));
+  int rc = cilqr_warp_costmap_device(h, s, h->d_src, sg, h->d_dst, dg, vx, vy, vtheta, bbox ? h->d_bbox : nullptr,
+                                     (int64_t*)h->d_oob);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(dst, h->d_dst, nd * sizeof(float), hipMemcpyDeviceToHost, s));
+  unsigned long long oob = 0;
+  HIP_TRY(hipMemcpyAsync(&oob, h->d_oob, sizeof(oob), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (n_out_of_range) *n_out_of_range = (int64_t)oob;
+  return CILQR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+// cilqr_internal.h — shared between the C-ABI translation unit and the HIP kernels (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cilqr.h"
+
+namespace cilqr {
+
+// Scalars the kernels need, derived once per handle from cilqr_params on the host (so that the libm calls
+// tan(steer_angle_*) are the host's, exactly as in the reference, I/Model.cpp:20 / I/Constraints.cpp:119-121).
+struct KParams {
+  double dt;             // timestep
+  double desired_speed;
+  double tolerance;
+  double w_acc, w_yawrate, w_pos, w_vel, w_obstacle;
+  double q1_acc, q2_acc, q1_yawrate, q2_yawrate;
+  double q1_front, q2_front, q1_rear, q2_rear;
+  double acc_max, acc_min;
+  double tan_steer_max, tan_steer_min;  // tan(steer_angle_max), tan(steer_angle_min)
+  double wheelbase, speed_max;
+  double t_safe, s_safe_a, s_safe_b, ego_rad, ego_front, ego_rear;
+  double lamb_factor, lamb_max;
+  int32_t max_iterations;
+  int32_t n_samples;  // num_of_local_wpts * 10 (I/Constraints.cpp:28)
+};
+
+struct SolveArgs {
+  const double* x0;
+  double* U;
+  const double* poly;
+  const double* xplan_fl;
+  const double* obs_pose;
+  const double* obs_dim;
+  const double* obs_weight;  // may be null
+  double* X_out;
+  double* J_out;        // may be null
+  int32_t* iters_out;   // may be null
+  int32_t* status_out;  // may be null
+  double* obs_tab;      // workspace: [B][M][6][N]
+  int32_t B, N, M;
+  uint32_t flags;
+  KParams kp;
+};
+
+// Launchers (defined in the .hip files). All are asynchronous on `stream`.
+hipError_t launch_solve(const SolveArgs& a, hipStream_t stream);
+size_t solve_lds_bytes(int N, int n_samples);
+
+hipError_t launch_argmin(const double* J, int B, double* out_pair, double* scratch, hipStream_t stream);
+size_t argmin_scratch_doubles(int B);
+
+struct WarpArgs {
+  const float* src;
+  float* dst;
+  const float* bbox;  // may be null
+  unsigned long long* n_oob;  // may be null
+  cilqr_map_geom sg, dg;
+  double vx, vy, sin_t, cos_t;
+};
+hipError_t launch_warp(const WarpArgs& a, hipStream_t stream);
+
+}  // namespace cilqr

@@ -1,0 +1,132 @@
+// costmap_warp.hip — rigid global→vehicle-frame costmap warp for gfx950 (MI355X).
+//
+// Reference: the per-cell loop of LocalCostmap::odomCallback (M/src/local_costmap.cpp:242-264) over the
+// grid_map index conventions (G/grid_map_core/src/GridMapMath.cpp:114-156, GridMap.cpp:45-62,160-166):
+//   destination cell (i,j) → centre C = (pos + len/2 - res/2) - res·(i,j)
+//   → g = Rot(theta)·C + (Vx,Vy) → source index trunc(-((g - len_g/2) - pos_g)/res_g), valid iff inside the source map
+//   → dst = src[index];  bbox(cell) > 90 overrides.
+// HBM-bound gather/scatter: 4 B read + 4 B write per destination cell (+4 B with the bbox layer).  Layout: float32
+// column-major (i fastest).  A workgroup owns a 64(i)×16(j) destination tile: lanes run along i, so destination
+// stores (and the bbox loads) are 256-B coalesced per wavefront, and the source footprint of a tile is a small rotated
+// rectangle that stays in L1/L2.  Tiles are dealt to XCDs in contiguous runs so neighbouring tiles (which share
+// source cache lines) share an L2.
+// The index arithmetic is fp64 with contraction OFF and IEEE division so that indices are bit-identical to the
+// reference's (an fma here would move cells that sit on a source-cell boundary).
+#include "cilqr_internal.h"
+
+namespace cilqr {
+
+namespace {
+
+constexpr int TILE_I = 64;
+constexpr int TILE_J = 16;
+constexpr int NTHREADS = 256;  // 4 wavefronts: wave w handles j = w, w+4, w+8, w+12 of the tile
+
+__global__ __launch_bounds__(NTHREADS) void warp_kernel(WarpArgs a, int tiles_i, int n_tiles) {
+#pragma clang fp contract(off)
+  // XCD-aware remap: workgroup ids are dealt round-robin over the 8 XCDs (speed only, never correctness).
+  int bid = blockIdx.x;
+  {
+    const int per = n_tiles / 8;
+    if (per > 0 && bid < per * 8) bid = (bid % 8) * per + bid / 8;
+  }
+  const int ti = bid % tiles_i, tj = bid / tiles_i;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = ti * TILE_I + lane;
+  const int drows = a.dg.rows, dcols = a.dg.cols;
+  if (i >= drows) return;
+
+  const double off_dx = 0.5 * a.dg.len_x - 0.5 * a.dg.res, off_dy = 0.5 * a.dg.len_y - 0.5 * a.dg.res;
+  const double Cx = (a.dg.pos_x + off_dx) + a.dg.res * (double)(-i);
+  const double off_sx = 0.5 * a.sg.len_x, off_sy = 0.5 * a.sg.len_y;
+  const double cxc = Cx * a.cos_t, cxs = Cx * a.sin_t;
+  unsigned long long oob = 0;
+#pragma unroll
+  for (int jj = 0; jj < TILE_J / 4; ++jj) {
+    const int j = tj * TILE_J + wave + 4 * jj;
+    if (j >= dcols) break;
+    const double Cy = (a.dg.pos_y + off_dy) + a.dg.res * (double)(-j);
+    const double x_og = (cxc - Cy * a.sin_t) + a.vx;
+    const double y_og = (cxs + Cy * a.cos_t) + a.vy;
+    // getIndexFromPosition / checkIfPositionWithinMap
+    const double nx = -(((x_og - off_sx) - a.sg.pos_x) / a.sg.res);
+    const double ny = -(((y_og - off_sy) - a.sg.pos_y) / a.sg.res);
+    const double tx = -1.0 * ((x_og - a.sg.pos_x) - off_sx);
+    const double ty = -1.0 * ((y_og - a.sg.pos_y) - off_sy);
+    const bool fin = (nx > -2e9 && nx < 2e9 && ny > -2e9 && ny < 2e9);
+    const int si = fin ? (int)nx : -1, sj = fin ? (int)ny : -1;
+    const bool ok = (tx >= 0.0 && ty >= 0.0 && tx < a.sg.len_x && ty < a.sg.len_y) &&
+                    (si >= 0 && sj >= 0 && si < a.sg.rows && sj < a.sg.cols);
+    const size_t lin = (size_t)j * drows + i;
+    float v;
+    if (ok) {
+      v = a.src[(size_t)sj * a.sg.rows + si];
+    } else {
+      v = __builtin_nanf("");
+      ++oob;
+    }
+    if (a.bbox) {
+      const float bb = a.bbox[lin];
+      if (bb > 90.0f) v = bb;
+    }
+    a.dst[lin] = v;
+  }
+  if (a.n_oob) {
+    // one atomic per wavefront
+    for (int o = 32; o > 0; o >>= 1) oob += __shfl_xor(oob, o, 64);
+    if (lane == 0 && oob) atomicAdd(a.n_oob, oob);
+  }
+}
+
+}  // namespace
+
+hipError_t launch_warp(const WarpArgs& a, hipStream_t stream) {
+  const int tiles_i = (a.dg.rows + TILE_I - 1) / TILE_I, tiles_j = (a.dg.cols + TILE_J - 1) / TILE_J;
+  const int n_tiles = tiles_i * tiles_j;
+  if (n_tiles <= 0) return hipSuccess;
+  hipLaunchKernelGGL(warp_kernel, dim3(n_tiles), dim3(NTHREADS), 0, stream, a, tiles_i, n_tiles);
+  return hipGetLastError();
+}
+
+// ---- batch min-cost selection ---------------------------------------------------------------------------------
+
+namespace {
+
+constexpr int AM_THREADS = 1024;
+
+// Lexicographic (J, index) minimum: strict-< first-minimum tie-break (I/Constraints.cpp:50 convention); NaN never wins.
+__device__ __forceinline__ void amin_merge(double& j0, int& i0, double j1, int i1) {
+  if (j1 < j0 || (j1 == j0 && i1 < i0)) { j0 = j1; i0 = i1; }
+}
+
+__global__ __launch_bounds__(AM_THREADS) void argmin_kernel(const double* J, int B, double* out_pair) {
+  __shared__ double sj[AM_THREADS / 64];
+  __shared__ int si[AM_THREADS / 64];
+  double bj = __builtin_huge_val();
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < B; i += AM_THREADS) amin_merge(bj, bi, J[i], i);
+  for (int o = 32; o > 0; o >>= 1) {
+    const double oj = __shfl_xor(bj, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    amin_merge(bj, bi, oj, oi);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { sj[wave] = bj; si[wave] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < AM_THREADS / 64; ++w) amin_merge(bj, bi, sj[w], si[w]);
+    out_pair[0] = bj;
+    out_pair[1] = (bi == 0x7fffffff) ? -1.0 : (double)bi;
+  }
+}
+
+}  // namespace
+
+size_t argmin_scratch_doubles(int) { return 0; }
+
+hipError_t launch_argmin(const double* J, int B, double* out_pair, double*, hipStream_t stream) {
+  hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(AM_THREADS), 0, stream, J, B, out_pair);
+  return hipGetLastError();
+}
+
+}  // namespace cilqr
