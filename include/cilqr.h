@@ -170,7 +170,7 @@ int cilqr_solve_batch(cilqr_handle* h, int B, int N, int M,
                       uint32_t flags);
 
 /* Same, with every pointer a DEVICE pointer on the handle's device and the work enqueued on `stream`
- * (a hipStream_t passed as void*; NULL = the handle's own stream).  Asynchronous: returns after launch. */
+ * (a hipStream_t passed as void*; NULL = the HIP null stream, as everywhere in HIP).  Asynchronous: returns after launch. */
 int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
                              const double* x0, double* U, const double* poly, const double* xplan_fl,
                              const double* obs_pose, const double* obs_dim, const double* obs_weight,
@@ -182,7 +182,13 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
  * is one all-gather of these 16-byte pairs (RCCL), done by the caller's communicator. */
 int cilqr_argmin_device(cilqr_handle* h, void* stream, int B, const double* J, double* out_pair);
 
-/* Blocks until everything enqueued on the handle's own stream has finished. */
+/* Diagnostics (the reference's only tracing is std::chrono around run_step, I/ilqr_uncertainty_node.cpp:117-124): while
+ * dev_buf != NULL, solves run a separately compiled, stamped instantiation of the kernel that writes, per solve, 8
+ * uint64 shader-clock totals {prologue, linearise, Riccati, forward, epilogue, #linearise, #Riccati, total} to
+ * dev_buf[B][8] (device memory owned by the caller).  NULL restores the production kernel.  Never use it when timing. */
+int cilqr_set_diag_buffer(cilqr_handle* h, uint64_t* dev_buf);
+
+/* Blocks until everything the host-pointer entry points enqueued on the handle's own stream has finished. */
 int cilqr_wait(cilqr_handle* h);
 
 /* --- costmap warp ----------------------------------------------------------------------------- */

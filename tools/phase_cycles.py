@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Per-phase shader-clock breakdown of the solve kernel on config 2 (diagnostic instantiation; not a timing run)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "uncertainty-aware-cilqr-for-trajectory-optimization_amd")]
+import numpy as np, torch
+import cilqr_amd
+from cilqr_amd import scenes
+B, N, M = int(os.environ.get("B", 1024)), int(os.environ.get("N", 50)), int(os.environ.get("M", 4))
+p = cilqr_amd.default_params(N)
+sc = scenes.make_static(B, N, M, p, scenes.SEED0 + 2)
+s = cilqr_amd.Solver(p, max_batch=B, max_horizon=N, max_obstacles=max(M, 1))
+dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+x0, U, poly, xpl = dv(sc["x0"]), dv(sc["U"]), dv(sc["poly"]), dv(sc["xplan_fl"])
+pose, dim = (dv(sc["obs_pose"]), dv(sc["obs_dim"])) if M else (None, None)
+X = torch.zeros(B, 4 * (N + 1), dtype=torch.float64, device="cuda"); J = torch.zeros(B, dtype=torch.float64, device="cuda")
+it = torch.zeros(B, dtype=torch.int32, device="cuda"); st = torch.zeros(B, dtype=torch.int32, device="cuda")
+diag = torch.zeros(B, 8, dtype=torch.int64, device="cuda")
+s.set_diag_buffer(diag.data_ptr())
+s.solve_batch_device(0, B, N, M, x0.data_ptr(), U.data_ptr(), poly.data_ptr(), xpl.data_ptr(), pose.data_ptr() if M else 0,
+                     dim.data_ptr() if M else 0, 0, X.data_ptr(), J.data_ptr(), it.data_ptr(), st.data_ptr())
+torch.cuda.synchronize()
+d = diag.cpu().numpy().astype(np.float64)
+nL, nR = d[:, 5], d[:, 6]
+print("solves", B, "N", N, "M", M)
+print("per-solve totals (cycles): mean %.0f  max %.0f" % (d[:, 7].mean(), d[:, 7].max()))
+print("prologue mean %.0f | epilogue mean %.0f" % (d[:, 0].mean(), d[:, 4].mean()))
+print("L per call: %.0f  (calls mean %.1f max %d)" % ((d[:, 1] / nL).mean(), nL.mean(), nL.max()))
+m = nR > 0
+print("R per call: %.0f -> %.0f per step" % ((d[m, 2] / nR[m]).mean(), (d[m, 2] / nR[m]).mean() / N))
+print("F per call: %.0f -> %.0f per step" % ((d[m, 3] / nR[m]).mean(), (d[m, 3] / nR[m]).mean() / N))
+w = int(np.argmax(d[:, 7]))
+print("slowest solve %d: pro %d L %d R %d F %d epi %d nL %d nR %d total %d" % ((w,) + tuple(int(v) for v in d[w])))

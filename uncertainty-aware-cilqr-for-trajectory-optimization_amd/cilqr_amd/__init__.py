@@ -20,7 +20,7 @@ EXIT_TOLERANCE, EXIT_LAMBDA_MAX, EXIT_MAX_ITER, EXIT_NUMERIC = 0, 1, 2, 3
 ABI_SYMBOLS = (
     "cilqr_params_default", "cilqr_abi_version", "cilqr_last_error", "cilqr_default_control_seq",
     "cilqr_local_plan", "cilqr_create", "cilqr_destroy", "cilqr_solve_batch", "cilqr_solve_batch_device",
-    "cilqr_argmin_device", "cilqr_wait", "cilqr_warp_costmap", "cilqr_warp_costmap_device", "cilqr_map_geom_set",
+    "cilqr_argmin_device", "cilqr_wait", "cilqr_set_diag_buffer", "cilqr_warp_costmap", "cilqr_warp_costmap_device", "cilqr_map_geom_set",
 )
 
 _dp = C.POINTER(C.c_double)
@@ -175,6 +175,9 @@ class Solver:
 
     def argmin_device(self, stream, B, J, out_pair):
         _check(lib().cilqr_argmin_device(self._h, _vp(stream), int(B), _vp(J), _vp(out_pair)))
+
+    def set_diag_buffer(self, dev_ptr):
+        _check(lib().cilqr_set_diag_buffer(self._h, _vp(dev_ptr)))
 
     def wait(self):
         _check(lib().cilqr_wait(self._h))

@@ -48,6 +48,7 @@ struct cilqr_handle {
   float *d_src, *d_dst, *d_bbox;
   size_t src_cap, dst_cap, bbox_cap;
   unsigned long long* d_oob;
+  unsigned long long* diag;  // caller-owned device buffer or null
 };
 
 namespace {
@@ -60,8 +61,9 @@ void derive(const cilqr_params& p, cilqr::KParams& k) {
   k.q1_acc = p.q1_acc; k.q2_acc = p.q2_acc; k.q1_yawrate = p.q1_yawrate; k.q2_yawrate = p.q2_yawrate;
   k.q1_front = p.q1_front; k.q2_front = p.q2_front; k.q1_rear = p.q1_rear; k.q2_rear = p.q2_rear;
   k.acc_max = p.acc_max; k.acc_min = p.acc_min;
-  k.tan_steer_max = tan(p.steer_angle_max);
-  k.tan_steer_min = tan(p.steer_angle_min);
+  k.yaw_hi = tan(p.steer_angle_max) / p.wheelbase;
+  k.yaw_lo = tan(p.steer_angle_min) / p.wheelbase;
+  k.half_dt2 = p.timestep * p.timestep / 2.0;
   k.wheelbase = p.wheelbase; k.speed_max = p.speed_max;
   k.t_safe = p.t_safe; k.s_safe_a = p.s_safe_a; k.s_safe_b = p.s_safe_b;
   k.ego_rad = p.ego_rad; k.ego_front = p.ego_front; k.ego_rear = p.ego_rear;
@@ -196,6 +198,12 @@ int cilqr_destroy(cilqr_handle* h) {
   return CILQR_OK;
 }
 
+int cilqr_set_diag_buffer(cilqr_handle* h, uint64_t* dev_buf) {
+  if (!h) return fail(CILQR_ERR_ARG, "null handle");
+  h->diag = (unsigned long long*)dev_buf;
+  return CILQR_OK;
+}
+
 int cilqr_wait(cilqr_handle* h) {
   if (!h) return fail(CILQR_ERR_ARG, "null handle");
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -216,10 +224,11 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
   a.obs_pose = obs_pose; a.obs_dim = obs_dim; a.obs_weight = M > 0 ? obs_weight : nullptr;
   a.X_out = X_out; a.J_out = J_out; a.iters_out = iters_out; a.status_out = status_out;
   a.obs_tab = h->d_obs_tab;
+  a.diag = h->diag;
   a.B = B; a.N = N; a.M = M; a.flags = flags;
   a.kp = h->kp;
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(cilqr::launch_solve(a, stream ? (hipStream_t)stream : h->stream));
+  HIP_TRY(cilqr::launch_solve(a, (hipStream_t)stream));
   return CILQR_OK;
 }
 
@@ -258,7 +267,7 @@ int cilqr_solve_batch(cilqr_handle* h, int B, int N, int M, const double* x0, do
 int cilqr_argmin_device(cilqr_handle* h, void* stream, int B, const double* J, double* out_pair) {
   if (!h || !J || !out_pair || B < 1) return fail(CILQR_ERR_ARG, "cilqr_argmin_device: bad argument");
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(cilqr::launch_argmin(J, B, out_pair, nullptr, stream ? (hipStream_t)stream : h->stream));
+  HIP_TRY(cilqr::launch_argmin(J, B, out_pair, nullptr, (hipStream_t)stream));
   return CILQR_OK;
 }
 
@@ -281,7 +290,7 @@ int cilqr_warp_costmap_device(cilqr_handle* h, void* stream, const float* src, c
   if (!h || !src || !sg || !dst || !dg) return fail(CILQR_ERR_ARG, "cilqr_warp_costmap: null argument");
   if (sg->rows < 1 || sg->cols < 1 || dg->rows < 1 || dg->cols < 1 || !(sg->res > 0.0) || !(dg->res > 0.0))
     return fail(CILQR_ERR_ARG, "cilqr_warp_costmap: bad geometry");
-  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipSetDevice(h->device));
   cilqr::WarpArgs a;
   a.src = src; a.dst = dst; a.bbox = bbox;

@@ -18,7 +18,8 @@ struct KParams {
   double q1_acc, q2_acc, q1_yawrate, q2_yawrate;
   double q1_front, q2_front, q1_rear, q2_rear;
   double acc_max, acc_min;
-  double tan_steer_max, tan_steer_min;  // tan(steer_angle_max), tan(steer_angle_min)
+  double yaw_hi, yaw_lo;  // tan(steer_angle_max)/wheelbase, tan(steer_angle_min)/wheelbase: yaw-rate bound per unit speed
+  double half_dt2;        // timestep²/2
   double wheelbase, speed_max;
   double t_safe, s_safe_a, s_safe_b, ego_rad, ego_front, ego_rear;
   double lamb_factor, lamb_max;
@@ -39,6 +40,7 @@ struct SolveArgs {
   int32_t* iters_out;   // may be null
   int32_t* status_out;  // may be null
   double* obs_tab;      // workspace: [B][M][6][N]
+  unsigned long long* diag;  // null, or [B][8] phase cycle totals (diagnostic instantiation)
   int32_t B, N, M;
   uint32_t flags;
   KParams kp;

@@ -52,19 +52,51 @@ struct State {
   double x, y, v, th, c, s;
 };
 
-// Model::forward_simulate, I/Model.cpp:17-30 (the clamps act on a copy of the control, :19-20).
+// sin and cos of one fp64 argument, ≤ ~1 ulp each: three-part Cody–Waite reduction by pi/2 (exact first step under fma
+// for |x| < 2^20·pi/2) followed by the classic degree-13 / degree-14 minimax kernels on [-pi/4, pi/4].  Larger arguments
+// (never met by a heading angle) take the library path.  The serial forward pass spends most of its dependent chain
+// here, so the ~35 instructions of this form (against ~160 for the library's general-range sincos) are what bounds a step.
+__device__ __forceinline__ void sincos_fast(double x, double* sn, double* cs) {
+  if (__builtin_expect(!(fabs(x) < 1.0e6), 0)) {
+    sincos(x, sn, cs);
+    return;
+  }
+  const double n = rint(x * 6.36619772367581382433e-01);  // 2/pi
+  double r = fma(-n, 1.57079632679489655800e+00, x);      // pi/2 head: exact
+  r = fma(-n, 6.12323399573676603587e-17, r);             // pi/2 - head
+  r = fma(-n, -1.49738490485916983278e-33, r);            // next part
+  const double z = r * r;
+  // sin kernel
+  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                               2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                               8.33333333332248946124e-03), -1.66666666666666324348e-01);
+  const double sr = fma(z * r, ps, r);
+  // cos kernel
+  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                               -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                               -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+  const double hz = 0.5 * z;
+  const double w = 1.0 - hz;
+  const double cr = w + (((1.0 - w) - hz) + z * (z * pc));
+  const int q = (int)n;
+  const double s0 = (q & 1) ? cr : sr;
+  const double c0 = (q & 1) ? sr : cr;
+  *sn = (q & 2) ? -s0 : s0;
+  *cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// Model::forward_simulate, I/Model.cpp:17-30 (the clamps act on a copy of the control, :19-20).  The yaw-rate bounds
+// v·tan(steer)/wheelbase are taken as v·(tan(steer)/wheelbase) with the quotient formed once on the host.
 __device__ __forceinline__ State dyn_step(const KParams& kp, const State& st, double u0, double u1) {
   const double a = fmax(fmin(u0, kp.acc_max), kp.acc_min);
-  const double hi = st.v * kp.tan_steer_max / kp.wheelbase;
-  const double lo = st.v * kp.tan_steer_min / kp.wheelbase;
-  const double w = fmax(fmin(u1, hi), lo);
-  const double adv = st.v * kp.dt + a * kp.dt * kp.dt / 2.0;
+  const double w = fmax(fmin(u1, st.v * kp.yaw_hi), st.v * kp.yaw_lo);
+  const double adv = st.v * kp.dt + a * kp.half_dt2;
   State n;
   n.x = st.x + st.c * adv;
   n.y = st.y + st.s * adv;
   n.v = fmin(fmax(st.v + a * kp.dt, 0.0), kp.speed_max);
   n.th = st.th + w * kp.dt;
-  sincos(n.th, &n.s, &n.c);
+  sincos_fast(n.th, &n.s, &n.c);
   return n;
 }
 
@@ -73,17 +105,48 @@ __device__ __forceinline__ void store_state(double* X, int t, const State& s) {
   r[0] = s.x; r[1] = s.y; r[2] = s.v; r[3] = s.th; r[4] = s.c; r[5] = s.s;
 }
 
-// Closest path sample to (px, py): strict-< first minimum (I/Constraints.cpp:43-56).
-__device__ __forceinline__ void closest_sample(const double* samp, int S, double px, double py, double& cx, double& cy) {
-  double bx = samp[0], by = samp[1];
-  double md = (bx - px) * (bx - px) + (by - py) * (by - py);
-  for (int s = 0; s < S; ++s) {
-    const double sx = samp[2 * s], sy = samp[2 * s + 1];
-    const double d = (sx - px) * (sx - px) + (sy - py) * (sy - py);
-    if (d < md) { md = d; bx = sx; by = sy; }
+// Uniform (per solve) description of the sample abscissae x_s = xf + dxs*s, for the windowed search below.
+struct SampleGrid {
+  double xf, inv_dxs;  // inv_dxs = 1/dxs (signed)
+  bool windowed;       // false: dxs is 0 or not finite → full scan
+};
+
+__device__ __forceinline__ double sample_dist(const double* samp, int s, double px, double py) {
+  const double sx = samp[2 * s], sy = samp[2 * s + 1];
+  return (sx - px) * (sx - px) + (sy - py) * (sy - py);
+}
+
+// Closest path sample to (px, py): index of the strict-< first minimum of the squared distance over ALL S samples
+// (I/Constraints.cpp:43-56), found without visiting all of them.  A sample can only reach the distance d_c of the
+// sample nearest in x if its own x-offset satisfies (x_s - px)² ≤ d_c, because fl(dx² + dy²) ≥ fl(dx²); the x_s are
+// equispaced, so that is an index window around (px - xf)/dxs.  The window is widened by two samples and a 1e-4
+// relative margin (≫ any rounding in its own computation), clamped to [0, S-1] and scanned in ascending order with
+// strict <, which yields exactly the reference's argmin, ties included.
+__device__ __forceinline__ int closest_sample(const double* samp, int S, const SampleGrid& g, double px, double py) {
+  int lo = 0, hi = S - 1;
+  if (g.windowed) {
+    const double fc = (px - g.xf) * g.inv_dxs;
+    const double fcc = fmin(fmax(fc, 0.0), (double)(S - 1));  // NaN → 0
+    const double dc = sample_dist(samp, (int)(fcc + 0.5), px, py);
+    const double hw = (double)(__builtin_sqrtf((float)dc) * 1.0001f) * fabs(g.inv_dxs) * 1.0001 + 2.0;
+    if (hw < 1.0e9) {  // false for NaN / overflow: keep the full range
+      lo = (int)fmin(fmax(fc - hw, 0.0), (double)(S - 1));
+      hi = (int)fmax(fmin(fc + hw + 1.0, (double)(S - 1)), 0.0);
+    }
   }
-  cx = bx;
-  cy = by;
+  double md = sample_dist(samp, lo, px, py);
+  int best = lo;
+  for (int s = lo + 1; s <= hi; s += 4) {
+    // four candidates per trip (indices past hi repeat hi: harmless under strict <), loads issued together
+    const int s1 = min(s + 1, hi), s2 = min(s + 2, hi), s3 = min(s + 3, hi);
+    const double d0 = sample_dist(samp, s, px, py), d1 = sample_dist(samp, s1, px, py);
+    const double d2 = sample_dist(samp, s2, px, py), d3 = sample_dist(samp, s3, px, py);
+    if (d0 < md) { md = d0; best = s; }
+    if (d1 < md) { md = d1; best = s1; }
+    if (d2 < md) { md = d2; best = s2; }
+    if (d3 < md) { md = d3; best = s3; }
+  }
+  return best;
 }
 
 // Stage cost of Constraints::get_J (I/Constraints.cpp:534-561) for one step.
@@ -95,8 +158,8 @@ __device__ __forceinline__ double stage_cost(const KParams& kp, double dx, doubl
 
 // Phase L.  Returns this lane's partial of J over its timesteps.
 __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int lane, const double* samp, int S,
-                                            const double* X, const double* U, double* rec, const double* tab,
-                                            const double* wts) {
+                                            const SampleGrid& grid, const double* X, const double* U, double* rec,
+                                            const double* tab, const double* wts) {
   double Jpart = 0.0;
   const double dt = kp.dt;
   for (int t = lane; t < N; t += WAVE) {
@@ -105,8 +168,8 @@ __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int
     const double u0 = U[2 * t], u1 = U[2 * t + 1];
 
     // --- tracking cost (I/Constraints.cpp:163-174)
-    double cx, cy;
-    closest_sample(samp, S, px, py, cx, cy);
+    const int cs = closest_sample(samp, S, grid, px, py);
+    const double cx = samp[2 * cs], cy = samp[2 * cs + 1];
     const double dx = px - cx, dy = py - cy, dv = v - kp.desired_speed;
     double lx0 = (2 * kp.w_pos) * dx;
     double lx1 = (2 * kp.w_pos) * dy;
@@ -151,8 +214,8 @@ __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int
     // --- control cost (I/Constraints.cpp:110-131)
     const double e1 = exp(kp.q2_acc * (u0 - kp.acc_max));
     const double e2 = exp(kp.q2_acc * (kp.acc_min - u0));
-    const double e3 = exp(kp.q2_yawrate * (u1 - v * kp.tan_steer_max / kp.wheelbase));
-    const double e4 = exp(kp.q2_yawrate * (v * kp.tan_steer_min / kp.wheelbase - u1));
+    const double e3 = exp(kp.q2_yawrate * (u1 - v * kp.yaw_hi));
+    const double e4 = exp(kp.q2_yawrate * (v * kp.yaw_lo - u1));
     const double sa = kp.q2_acc * kp.q1_acc, sy = kp.q2_yawrate * kp.q1_yawrate;
     const double ma = kp.q2_acc * kp.q2_acc * kp.q1_acc, my = kp.q2_yawrate * kp.q2_yawrate * kp.q1_yawrate;
     const double lu0 = (sa * e1 - sa * e2) + (2 * kp.w_acc) * u0;
@@ -163,7 +226,7 @@ __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int
     // --- A/B entries at (v_{t+1}, theta_{t+1}, a_t) (I/iLQR.cpp:102-106, I/Model.cpp:100-155)
     const double* xn = X + (t + 1) * XR;
     const double vn = xn[2], cn = xn[4], sn = xn[5];
-    const double adv = vn * dt + 0.5 * u0 * dt * dt;
+    const double adv = vn * dt + u0 * kp.half_dt2;
     double* r = rec + t * REC;
     r[0] = lx0; r[1] = lx1; r[2] = lx2;
     r[3] = h00; r[4] = h01; r[5] = h11;
@@ -172,106 +235,114 @@ __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int
     r[11] = dt * sn;            // beta : A(2,1)
     r[12] = (-1) * sn * adv;    // gamma: A(3,0)
     r[13] = cn * adv;           // delta: A(3,1)
-    r[14] = dt * dt * cn / 2.0; // p    : B(0,0)
-    r[15] = dt * dt * sn / 2.0; // q    : B(0,1)
+    r[14] = kp.half_dt2 * cn;   // p    : B(0,0)
+    r[15] = kp.half_dt2 * sn;   // q    : B(0,1)
   }
   return Jpart;
 }
 
 // get_J only (used once after an accepted last iteration).
 __device__ __forceinline__ double cost_only(const KParams& kp, int N, int lane, const double* samp, int S,
-                                            const double* X, const double* U) {
+                                            const SampleGrid& grid, const double* X, const double* U) {
   double Jpart = 0.0;
   for (int t = lane; t < N; t += WAVE) {
     const double* xr = X + t * XR;
-    double cx, cy;
-    closest_sample(samp, S, xr[0], xr[1], cx, cy);
+    const int cs = closest_sample(samp, S, grid, xr[0], xr[1]);
+    const double cx = samp[2 * cs], cy = samp[2 * cs + 1];
     Jpart += stage_cost(kp, xr[0] - cx, xr[1] - cy, xr[2] - kp.desired_speed, U[2 * t], U[2 * t + 1]);
   }
   return Jpart;
 }
 
-// Phase R: iLQR::backward_pass recursion (I/iLQR.cpp:108-191).  All lanes compute the same values.
-// Returns false when Q_uu is not finite (the reference's EigenSolver path cannot produce a real
-// decomposition there).
+// One per-step linearisation record held in registers.
+struct Rec {
+  double lx0, lx1, lx2, l00, l01, l11, lu0, lu1, luu0, luu1, al, be, ga, de, p, q;
+};
+__device__ __forceinline__ Rec load_rec(const double* rec, int j) {
+  const double* r = rec + j * REC;
+  Rec o;
+  o.lx0 = r[0]; o.lx1 = r[1]; o.lx2 = r[2]; o.l00 = r[3]; o.l01 = r[4]; o.l11 = r[5];
+  o.lu0 = r[6]; o.lu1 = r[7]; o.luu0 = r[8]; o.luu1 = r[9];
+  o.al = r[10]; o.be = r[11]; o.ga = r[12]; o.de = r[13]; o.p = r[14]; o.q = r[15];
+  return o;
+}
+
+// Phase R: iLQR::backward_pass recursion (I/iLQR.cpp:108-191).  All lanes compute the same values (operands are
+// broadcast LDS reads, prefetched one step ahead); lane 0 stores the gains.
+//
+// With fx = [[1,0,0,0],[0,1,0,0],[al,be,1,0],[ga,de,0,1]] and fu = [[p,q,dt,0],[0,0,0,dt]] (the reference's
+// stored-transposed Jacobians, I/Model.cpp:100-155) the products of :149-153 reduce to a handful of fused
+// multiply-adds per entry.  V_xx, Q_xx and Q_uu are carried as symmetric matrices (upper triangle): the reference
+// computes both triangles, which agree to rounding.
+// Returns false when Q_uu is not finite (the reference's EigenSolver path cannot produce a real decomposition there).
 __device__ __forceinline__ bool riccati(const KParams& kp, int N, int lane, const double* rec, double* kK, double lamb) {
   const double dt = kp.dt;
-  double Vx[4], V[4][4];
-  {
-    const double* r = rec + (N - 1) * REC;  // :108-113: terminal value = stage N-1
-    Vx[0] = r[0]; Vx[1] = r[1]; Vx[2] = r[2]; Vx[3] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) V[i][j] = 0.0;
-    V[0][0] = r[3]; V[0][1] = r[4]; V[1][0] = r[4]; V[1][1] = r[5];
-    V[2][2] = kp.w_vel * 2;
-  }
+  Rec c = load_rec(rec, N - 1);
+  // :108-113: terminal value = stage N-1
+  double x0 = c.lx0, x1 = c.lx1, x2 = c.lx2, x3 = 0.0;                     // V_x
+  double v00 = c.l00, v01 = c.l01, v02 = 0.0, v03 = 0.0, v11 = c.l11, v12 = 0.0, v13 = 0.0;
+  double v22 = kp.w_vel * 2, v23 = 0.0, v33 = 0.0;                          // V_xx (upper triangle)
   bool ok = true;
   for (int j = N - 1; j >= 0; --j) {
-    const double* r = rec + j * REC;
-    const double lx0 = r[0], lx1 = r[1], lx2 = r[2], l00 = r[3], l01 = r[4], l11 = r[5];
-    const double lu0 = r[6], lu1 = r[7], luu0 = r[8], luu1 = r[9];
-    const double al = r[10], be = r[11], ga = r[12], de = r[13], p = r[14], q = r[15];
+    const Rec nx = load_rec(rec, j > 0 ? j - 1 : 0);  // prefetch
+    const double al = c.al, be = c.be, ga = c.ga, de = c.de, p = c.p, q = c.q;
 
-    // Q_x = l_x + fx*V_x ; Q_u = l_u + fu*V_x (:149-150); fx = [[1,0,0,0],[0,1,0,0],[al,be,1,0],[ga,de,0,1]],
-    // fu = [[p,q,dt,0],[0,0,0,dt]] (the stored-transposed Jacobians).
-    double Qx[4], Qu[2];
-    Qx[0] = lx0 + Vx[0];
-    Qx[1] = lx1 + Vx[1];
-    Qx[2] = lx2 + (al * Vx[0] + be * Vx[1] + Vx[2]);
-    Qx[3] = 0.0 + (ga * Vx[0] + de * Vx[1] + Vx[3]);
-    Qu[0] = lu0 + (p * Vx[0] + q * Vx[1] + dt * Vx[2]);
-    Qu[1] = lu1 + dt * Vx[3];
+    // Q_x = l_x + fx V_x ; Q_u = l_u + fu V_x (:149-150)
+    const double qx0 = c.lx0 + x0;
+    const double qx1 = c.lx1 + x1;
+    const double qx2 = c.lx2 + (al * x0 + be * x1 + x2);
+    const double qx3 = ga * x0 + de * x1 + x3;
+    const double qu0 = c.lu0 + (p * x0 + q * x1 + dt * x2);
+    const double qu1 = c.lu1 + dt * x3;
 
-    // T = fx*V ; Q_xx = l_xx + T*fx' (:151)
-    double T[4][4], Qxx[4][4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      T[0][c] = V[0][c];
-      T[1][c] = V[1][c];
-      T[2][c] = al * V[0][c] + be * V[1][c] + V[2][c];
-      T[3][c] = ga * V[0][c] + de * V[1][c] + V[3][c];
-    }
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      Qxx[rr][0] = T[rr][0];
-      Qxx[rr][1] = T[rr][1];
-      Qxx[rr][2] = al * T[rr][0] + be * T[rr][1] + T[rr][2];
-      Qxx[rr][3] = ga * T[rr][0] + de * T[rr][1] + T[rr][3];
-    }
-    Qxx[0][0] += l00; Qxx[0][1] += l01; Qxx[1][0] += l01; Qxx[1][1] += l11;
-    Qxx[2][2] += kp.w_vel * 2;
+    // T = fx V (rows 2, 3) ; Q_xx = l_xx + T fx' (:151)
+    const double t20 = al * v00 + be * v01 + v02;
+    const double t21 = al * v01 + be * v11 + v12;
+    const double t22 = al * v02 + be * v12 + v22;
+    const double t23 = al * v03 + be * v13 + v23;
+    const double t30 = ga * v00 + de * v01 + v03;
+    const double t31 = ga * v01 + de * v11 + v13;
+    const double t32 = ga * v02 + de * v12 + v23;
+    const double t33 = ga * v03 + de * v13 + v33;
+    const double q00 = v00 + c.l00, q01 = v01 + c.l01, q11 = v11 + c.l11;
+    const double q02 = t20, q12 = t21, q03 = t30, q13 = t31;
+    const double q22 = (al * t20 + be * t21 + t22) + kp.w_vel * 2;
+    const double q23 = ga * t20 + de * t21 + t23;
+    const double q33 = ga * t30 + de * t31 + t33;
+    (void)t32;
 
-    // E = fu*V ; Q_ux = E*fx' ; Q_uu = l_uu + E*fu' (:152-153)
-    double E[2][4], Qux[2][4], Quu[2][2];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      E[0][c] = p * V[0][c] + q * V[1][c] + dt * V[2][c];
-      E[1][c] = dt * V[3][c];
-    }
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      Qux[rr][0] = E[rr][0];
-      Qux[rr][1] = E[rr][1];
-      Qux[rr][2] = al * E[rr][0] + be * E[rr][1] + E[rr][2];
-      Qux[rr][3] = ga * E[rr][0] + de * E[rr][1] + E[rr][3];
-      Quu[rr][0] = p * E[rr][0] + q * E[rr][1] + dt * E[rr][2];
-      Quu[rr][1] = dt * E[rr][3];
-    }
-    Quu[0][0] += luu0;
-    Quu[1][1] += luu1;
-
-    // Regularised inverse V*diag(1/(max(eig,0)+lamb))*V' (:155-175) in closed form for the symmetric 2×2:
-    // with h = (a-d)/2, rr = sqrt(h²+b²), c2 = h/rr, s2 = b/rr: inverse = (d1+d2)/2·I + (d1-d2)/2·[[c2,s2],[s2,-c2]].
-    const double a = Quu[0][0], d = Quu[1][1], b = 0.5 * (Quu[0][1] + Quu[1][0]);
+    // E = fu V ; Q_ux = E fx' ; Q_uu = l_uu + E fu' (:152-153)
+    const double e00 = p * v00 + q * v01 + dt * v02;
+    const double e01 = p * v01 + q * v11 + dt * v12;
+    const double e02 = p * v02 + q * v12 + dt * v22;
+    const double e03 = p * v03 + q * v13 + dt * v23;
+    const double e10 = dt * v03, e11 = dt * v13, e12 = dt * v23, e13 = dt * v33;
+    const double ux00 = e00, ux01 = e01;
+    const double ux02 = al * e00 + be * e01 + e02;
+    const double ux03 = ga * e00 + de * e01 + e03;
+    const double ux10 = e10, ux11 = e11;
+    const double ux12 = al * e10 + be * e11 + e12;
+    const double ux13 = ga * e10 + de * e11 + e13;
+    const double a = (p * e00 + q * e01 + dt * e02) + c.luu0;
+    const double b = dt * e03;
+    const double d = dt * e13 + c.luu1;
     if (!(a == a) || !(b == b) || !(d == d)) { ok = false; break; }
+
+    // Regularised inverse V diag(1/(max(eig,0)+lamb)) V' (:155-175).  Positive semi-definite Q_uu (always, when l_xx
+    // and l_uu are: barrier Hessians are rank-one PSD): both eigenvalues pass the clamp and the result is
+    // inv(Q_uu + lamb I), formed from the adjugate with a single division.  Otherwise the clamped eigen form:
+    // with h = (a-d)/2, r = sqrt(h²+b²): inverse = (d1+d2)/2·I + (d1-d2)/2·[[h,b],[b,-h]]/r.
     double i00, i01, i11;
-    {
+    if (a * d - b * b >= 0.0 && a + d >= 0.0) {
+      const double ar = a + lamb, dr = d + lamb;
+      const double rdet = 1.0 / (ar * dr - b * b);
+      i00 = dr * rdet;
+      i11 = ar * rdet;
+      i01 = -b * rdet;
+    } else {
       const double mm = 0.5 * (a + d), h = 0.5 * (a - d);
       const double rad = sqrt(h * h + b * b);
-      const double e_hi = mm + rad, e_lo = mm - rad;
-      const double d1 = 1.0 / (fmax(e_hi, 0.0) + lamb), d2 = 1.0 / (fmax(e_lo, 0.0) + lamb);
+      const double d1 = 1.0 / (fmax(mm + rad, 0.0) + lamb), d2 = 1.0 / (fmax(mm - rad, 0.0) + lamb);
       const double hs = 0.5 * (d1 + d2), hd = 0.5 * (d1 - d2);
       double c2 = 1.0, s2 = 0.0;
       if (rad > 0.0) { c2 = h / rad; s2 = b / rad; }
@@ -280,62 +351,96 @@ __device__ __forceinline__ bool riccati(const KParams& kp, int N, int lane, cons
       i01 = hd * s2;
     }
 
-    // k = -Qinv*Q_u ; K = -Qinv*Q_ux (:177-178)
-    double kj[2], Kj[2][4];
-    kj[0] = -(i00 * Qu[0] + i01 * Qu[1]);
-    kj[1] = -(i01 * Qu[0] + i11 * Qu[1]);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      Kj[0][c] = -(i00 * Qux[0][c] + i01 * Qux[1][c]);
-      Kj[1][c] = -(i01 * Qux[0][c] + i11 * Qux[1][c]);
-    }
+    // k = -Qinv Q_u ; K = -Qinv Q_ux (:177-178)
+    const double k0 = -(i00 * qu0 + i01 * qu1);
+    const double k1 = -(i01 * qu0 + i11 * qu1);
+    const double K00 = -(i00 * ux00 + i01 * ux10), K01 = -(i00 * ux01 + i01 * ux11);
+    const double K02 = -(i00 * ux02 + i01 * ux12), K03 = -(i00 * ux03 + i01 * ux13);
+    const double K10 = -(i01 * ux00 + i11 * ux10), K11 = -(i01 * ux01 + i11 * ux11);
+    const double K12 = -(i01 * ux02 + i11 * ux12), K13 = -(i01 * ux03 + i11 * ux13);
 
-    // G = K'*Q_uu (unregularised Q_uu) ; V_x = Q_x - G*k ; V_xx = Q_xx - G*K (:180-181)
-    double G[4][2];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      G[rr][0] = Kj[0][rr] * Quu[0][0] + Kj[1][rr] * Quu[1][0];
-      G[rr][1] = Kj[0][rr] * Quu[0][1] + Kj[1][rr] * Quu[1][1];
-    }
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      Vx[rr] = Qx[rr] - (G[rr][0] * kj[0] + G[rr][1] * kj[1]);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) V[rr][c] = Qxx[rr][c] - (G[rr][0] * Kj[0][c] + G[rr][1] * Kj[1][c]);
-    }
+    // G = K' Q_uu (unregularised) ; V_x = Q_x - G k ; V_xx = Q_xx - G K (:180-181)
+    const double g00 = K00 * a + K10 * b, g01 = K00 * b + K10 * d;
+    const double g10 = K01 * a + K11 * b, g11 = K01 * b + K11 * d;
+    const double g20 = K02 * a + K12 * b, g21 = K02 * b + K12 * d;
+    const double g30 = K03 * a + K13 * b, g31 = K03 * b + K13 * d;
+    x0 = qx0 - (g00 * k0 + g01 * k1);
+    x1 = qx1 - (g10 * k0 + g11 * k1);
+    x2 = qx2 - (g20 * k0 + g21 * k1);
+    x3 = qx3 - (g30 * k0 + g31 * k1);
+    v00 = q00 - (g00 * K00 + g01 * K10);
+    v01 = q01 - (g00 * K01 + g01 * K11);
+    v02 = q02 - (g00 * K02 + g01 * K12);
+    v03 = q03 - (g00 * K03 + g01 * K13);
+    v11 = q11 - (g10 * K01 + g11 * K11);
+    v12 = q12 - (g10 * K02 + g11 * K12);
+    v13 = q13 - (g10 * K03 + g11 * K13);
+    v22 = q22 - (g20 * K02 + g21 * K12);
+    v23 = q23 - (g20 * K03 + g21 * K13);
+    v33 = q33 - (g30 * K03 + g31 * K13);
 
     if (lane == 0) {
       double* o = kK + j * KR;
-      o[0] = kj[0]; o[1] = kj[1];
-      o[2] = Kj[0][0]; o[3] = Kj[0][1]; o[4] = Kj[0][2]; o[5] = Kj[0][3];
-      o[6] = Kj[1][0]; o[7] = Kj[1][1]; o[8] = Kj[1][2]; o[9] = Kj[1][3];
+      o[0] = k0; o[1] = k1;
+      o[2] = K00; o[3] = K01; o[4] = K02; o[5] = K03;
+      o[6] = K10; o[7] = K11; o[8] = K12; o[9] = K13;
     }
+    c = nx;
   }
   return ok;
 }
 
-// Phase F: iLQR::forward_pass (I/iLQR.cpp:68-86).  All lanes compute the same values; lane 0 stores.
+// Phase F: iLQR::forward_pass (I/iLQR.cpp:68-86).  All lanes compute the same values; lane 0 stores.  The operands of
+// step i+1 (old state, old control, gains) are read while step i computes.
+struct FwdIn {
+  double x, y, v, th, u0, u1, g[KR];
+};
+__device__ __forceinline__ FwdIn load_fwd(const double* X, const double* U, const double* kK, int i) {
+  FwdIn o;
+  const double* xo = X + i * XR;
+  o.x = xo[0]; o.y = xo[1]; o.v = xo[2]; o.th = xo[3];
+  o.u0 = U[2 * i]; o.u1 = U[2 * i + 1];
+  const double* g = kK + i * KR;
+#pragma unroll
+  for (int k = 0; k < KR; ++k) o.g[k] = g[k];
+  return o;
+}
+
 __device__ __forceinline__ void forward(const KParams& kp, int N, int lane, const double* X, const double* U,
                                         const double* kK, double* Xn, double* Un) {
   State s;
   s.x = X[0]; s.y = X[1]; s.v = X[2]; s.th = X[3]; s.c = X[4]; s.s = X[5];
   if (lane == 0) store_state(Xn, 0, s);
+  FwdIn c = load_fwd(X, U, kK, 0);
   for (int i = 0; i < N; ++i) {
-    const double* xo = X + i * XR;
-    const double* g = kK + i * KR;
-    const double d0 = s.x - xo[0], d1 = s.y - xo[1], d2 = s.v - xo[2], d3 = s.th - xo[3];
-    const double u0 = U[2 * i] + g[0] + (g[2] * d0 + g[3] * d1 + g[4] * d2 + g[5] * d3);
-    const double u1 = U[2 * i + 1] + g[1] + (g[6] * d0 + g[7] * d1 + g[8] * d2 + g[9] * d3);
+    const FwdIn nx = load_fwd(X, U, kK, i + 1 < N ? i + 1 : i);
+    const double d0 = s.x - c.x, d1 = s.y - c.y, d2 = s.v - c.v, d3 = s.th - c.th;
+    const double u0 = c.u0 + c.g[0] + (c.g[2] * d0 + c.g[3] * d1 + c.g[4] * d2 + c.g[5] * d3);
+    const double u1 = c.u1 + c.g[1] + (c.g[6] * d0 + c.g[7] * d1 + c.g[8] * d2 + c.g[9] * d3);
     s = dyn_step(kp, s, u0, u1);
     if (lane == 0) {
       Un[2 * i] = u0;
       Un[2 * i + 1] = u1;
       store_state(Xn, i + 1, s);
     }
+    c = nx;
   }
 }
 
+// DIAG: per-solve shader-clock totals by phase, written to a.diag[b][8] = {prologue, L, R, F, epilogue, L count, R count,
+// total}.  A separate instantiation so that the production kernel carries no stamps.
+// TABLDS: the obstacle table of the solve lives in LDS (chosen by the launcher when it fits beside the rest at the
+// wanted residency) instead of the global workspace.
+template <bool DIAG, bool TABLDS>
 __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
+  unsigned long long tk0 = 0, tk = 0, c_pro = 0, c_L = 0, c_R = 0, c_F = 0, n_L = 0, n_R = 0;
+  if (DIAG) tk0 = tk = __builtin_readcyclecounter();
+#define CILQR_STAMP(acc)                                 \
+  if (DIAG) {                                            \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    acc += now_ - tk;                                    \
+    tk = now_;                                           \
+  }
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
@@ -350,12 +455,17 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   double* Ub = Ua + 2 * N;
   double* rec = Ub + 2 * N;
   double* kK = rec + N * REC;
+  double* tab = TABLDS ? kK + N * KR : a.obs_tab + (size_t)b * M * TABF * N;
 
   // ---- prologue -------------------------------------------------------------------------------------------
+  SampleGrid grid;
   {  // path samples, I/Constraints.cpp:28-42 (ascending powers by repeated multiplication)
     const double* pc = a.poly + (size_t)b * CILQR_POLY_COEFFS;
     const double xf = a.xplan_fl[2 * b], xl = a.xplan_fl[2 * b + 1];
     const double dxs = (xl - xf) / (double)S;
+    grid.xf = xf;
+    grid.inv_dxs = 1.0 / dxs;
+    grid.windowed = fabs(grid.inv_dxs) < 1.0e300 && fabs(dxs) < 1.0e300 && dxs != 0.0;  // finite, non-zero spacing
     for (int s = lane; s < S; s += WAVE) {
       const double x = xf + dxs * s;
       double y = 0.0, pw = 1.0;
@@ -371,7 +481,6 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   double* Ug = a.U + (size_t)b * 2 * N;
   for (int i = lane; i < 2 * N; i += WAVE) Ua[i] = Ug[i];
 
-  double* tab = a.obs_tab + (size_t)b * M * TABF * N;
   const double* wts = a.obs_weight ? a.obs_weight + (size_t)b * M : nullptr;
   for (int m = 0; m < M; ++m) {  // obstacle table, I/Obstacle.cpp:41-62
     for (int t = lane; t < N; t += WAVE) {
@@ -396,7 +505,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
     const double* x0 = a.x0 + (size_t)b * 4;
     State s;
     s.x = x0[0]; s.y = x0[1]; s.v = x0[2]; s.th = x0[3];
-    sincos(s.th, &s.s, &s.c);
+    sincos_fast(s.th, &s.s, &s.c);
     if (lane == 0) store_state(Xa, 0, s);
     for (int i = 0; i < N; ++i) {
       s = dyn_step(kp, s, Ua[2 * i], Ua[2 * i + 1]);
@@ -405,6 +514,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   }
   __syncthreads();
 
+  CILQR_STAMP(c_pro)
   // ---- iteration loop, I/iLQR.cpp:204-239 --------------------------------------------------------------------
   double* Xc = Xa;
   double* Uc = Ua;
@@ -419,9 +529,11 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
     ++iters;
     // The reference evaluates backward_pass, forward_pass, then J_new = get_J(X, U) on the CURRENT X, U (:213-217).
     // The linearisation and J share their closest-point searches, so they are computed together, first.
-    J_new = readfirstlane_f64(wave_sum(linearize(kp, N, M, lane, samp, S, Xc, Uc, rec, tab, wts)));
+    J_new = readfirstlane_f64(wave_sum(linearize(kp, N, M, lane, samp, S, grid, Xc, Uc, rec, tab, wts)));
     j_valid = true;
     __syncthreads();
+    CILQR_STAMP(c_L)
+    if (DIAG) ++n_L;
     const bool accept = J_new < J_old;
     if (!accept && !faithful) {
       // A rejection leaves X, U untouched, so every later iteration recomputes the same J_new == J_old and
@@ -436,8 +548,11 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
     }
     if (!riccati(kp, N, lane, rec, kK, lamb)) { status = CILQR_EXIT_NUMERIC; break; }
     __syncthreads();
+    CILQR_STAMP(c_R)
+    if (DIAG) ++n_R;
     forward(kp, N, lane, Xc, Uc, kK, Xn, Un);
     __syncthreads();
+    CILQR_STAMP(c_F)
     if (accept) {
       double* t0 = Xc; Xc = Xn; Xn = t0;
       double* t1 = Uc; Uc = Un; Un = t1;
@@ -456,13 +571,19 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   double* Xg = a.X_out + (size_t)b * 4 * (N + 1);
   for (int i = lane; i < 4 * (N + 1); i += WAVE) Xg[i] = Xc[(i >> 2) * XR + (i & 3)];
   if (a.J_out) {
-    if (!j_valid) J_new = readfirstlane_f64(wave_sum(cost_only(kp, N, lane, samp, S, Xc, Uc)));
+    if (!j_valid) J_new = readfirstlane_f64(wave_sum(cost_only(kp, N, lane, samp, S, grid, Xc, Uc)));
     if (lane == 0) a.J_out[b] = J_new;
   }
   if (lane == 0) {
     if (a.iters_out) a.iters_out[b] = iters;
     if (a.status_out) a.status_out[b] = status;
   }
+  if (DIAG && lane == 0 && a.diag) {
+    const unsigned long long now_ = __builtin_readcyclecounter();
+    unsigned long long* o = a.diag + (size_t)b * 8;
+    o[0] = c_pro; o[1] = c_L; o[2] = c_R; o[3] = c_F; o[4] = now_ - tk; o[5] = n_L; o[6] = n_R; o[7] = now_ - tk0;
+  }
+#undef CILQR_STAMP
 }
 
 }  // namespace
@@ -474,8 +595,18 @@ size_t solve_lds_bytes(int N, int n_samples) {
 
 hipError_t launch_solve(const SolveArgs& a, hipStream_t stream) {
   if (a.B <= 0) return hipSuccess;
-  const size_t lds = solve_lds_bytes(a.N, a.kp.n_samples);
-  hipLaunchKernelGGL(cilqr_solve_kernel, dim3(a.B), dim3(WAVE), lds, stream, a);
+  size_t lds = solve_lds_bytes(a.N, a.kp.n_samples);
+  // Keep the obstacle table in LDS while a workgroup stays within 32 KiB (≥ 5 solves resident per CU of 160 KiB).
+  const size_t tab_bytes = (size_t)a.M * TABF * a.N * sizeof(double);
+  const bool tab_lds = a.M > 0 && lds + tab_bytes <= 32 * 1024;
+  if (tab_lds) lds += tab_bytes;
+  if (a.diag) {
+    if (tab_lds) hipLaunchKernelGGL((cilqr_solve_kernel<true, true>), dim3(a.B), dim3(WAVE), lds, stream, a);
+    else hipLaunchKernelGGL((cilqr_solve_kernel<true, false>), dim3(a.B), dim3(WAVE), lds, stream, a);
+  } else {
+    if (tab_lds) hipLaunchKernelGGL((cilqr_solve_kernel<false, true>), dim3(a.B), dim3(WAVE), lds, stream, a);
+    else hipLaunchKernelGGL((cilqr_solve_kernel<false, false>), dim3(a.B), dim3(WAVE), lds, stream, a);
+  }
   return hipGetLastError();
 }
 
