@@ -254,177 +254,317 @@ __device__ __forceinline__ double cost_only(const KParams& kp, int N, int lane, 
   return Jpart;
 }
 
+// ---- single-instruction helpers -----------------------------------------------------------------------------------
+// One wavefront per SIMD issues one instruction every ~4.5 cycles whatever its kind (measured, tools/ubench_fp64.hip),
+// so the serial phases are priced in instructions.  These keep hipcc from adding canonicalising v_max around
+// fmin/fmax and from re-materialising 64-bit literals with s_mov pairs inside the loops.
+__device__ __forceinline__ double vmin(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double vmax(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// Pins a loop-invariant value in a vector register: after this the compiler cannot fold it back into a literal.
+#define CILQR_PIN(x) asm volatile("" : "+v"(x))
+
+// 1/x by v_rcp_f64 and two Newton steps (≤ ~1 ulp; x is a well-scaled positive determinant here).
+__device__ __forceinline__ double rcp_newton(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
 // One per-step linearisation record held in registers.
 struct Rec {
   double lx0, lx1, lx2, l00, l01, l11, lu0, lu1, luu0, luu1, al, be, ga, de, p, q;
 };
-__device__ __forceinline__ Rec load_rec(const double* rec, int j) {
+__device__ __forceinline__ void load_rec(Rec& o, const double* rec, int j) {
   const double* r = rec + j * REC;
-  Rec o;
   o.lx0 = r[0]; o.lx1 = r[1]; o.lx2 = r[2]; o.l00 = r[3]; o.l01 = r[4]; o.l11 = r[5];
   o.lu0 = r[6]; o.lu1 = r[7]; o.luu0 = r[8]; o.luu1 = r[9];
   o.al = r[10]; o.be = r[11]; o.ga = r[12]; o.de = r[13]; o.p = r[14]; o.q = r[15];
-  return o;
 }
 
-// Phase R: iLQR::backward_pass recursion (I/iLQR.cpp:108-191).  All lanes compute the same values (operands are
-// broadcast LDS reads, prefetched one step ahead); lane 0 stores the gains.
+// Value function carried by the backward recursion: V_x and the upper triangle of the symmetric V_xx.
+struct Value {
+  double x0, x1, x2, x3;
+  double v00, v01, v02, v03, v11, v12, v13, v22, v23, v33;
+};
+
+// One step of iLQR::backward_pass (I/iLQR.cpp:133-191).
 //
 // With fx = [[1,0,0,0],[0,1,0,0],[al,be,1,0],[ga,de,0,1]] and fu = [[p,q,dt,0],[0,0,0,dt]] (the reference's
-// stored-transposed Jacobians, I/Model.cpp:100-155) the products of :149-153 reduce to a handful of fused
-// multiply-adds per entry.  V_xx, Q_xx and Q_uu are carried as symmetric matrices (upper triangle): the reference
-// computes both triangles, which agree to rounding.
-// Returns false when Q_uu is not finite (the reference's EigenSolver path cannot produce a real decomposition there).
-__device__ __forceinline__ bool riccati(const KParams& kp, int N, int lane, const double* rec, double* kK, double lamb) {
-  const double dt = kp.dt;
-  Rec c = load_rec(rec, N - 1);
-  // :108-113: terminal value = stage N-1
-  double x0 = c.lx0, x1 = c.lx1, x2 = c.lx2, x3 = 0.0;                     // V_x
-  double v00 = c.l00, v01 = c.l01, v02 = 0.0, v03 = 0.0, v11 = c.l11, v12 = 0.0, v13 = 0.0;
-  double v22 = kp.w_vel * 2, v23 = 0.0, v33 = 0.0;                          // V_xx (upper triangle)
-  bool ok = true;
-  for (int j = N - 1; j >= 0; --j) {
-    const Rec nx = load_rec(rec, j > 0 ? j - 1 : 0);  // prefetch
-    const double al = c.al, be = c.be, ga = c.ga, de = c.de, p = c.p, q = c.q;
+// stored-transposed Jacobians, I/Model.cpp:100-155) the products of :149-153 reduce to one or two fused multiply-adds
+// per entry.  V_xx, Q_xx and Q_uu are carried as symmetric matrices (the reference computes both triangles, which
+// agree to rounding).  Returns false when Q_uu is not finite (the reference's EigenSolver cannot give a real
+// decomposition there).
+// FAST: branch-free positive-semi-definite form; steps whose Q_uu fails the test (or is NaN) are OR-ed into `suspect`
+// (a wavefront-uniform lane mask) and the caller redoes the whole pass with FAST = false, which handles them.
+template <bool FAST>
+__device__ __forceinline__ bool riccati_step(const Rec& c, Value& V, double dt, double two_wvel, double lamb, double* out,
+                                             unsigned long long& suspect) {
+  const double al = c.al, be = c.be, ga = c.ga, de = c.de, p = c.p, q = c.q;
+  const double x0 = V.x0, x1 = V.x1, x2 = V.x2, x3 = V.x3;
+  const double v00 = V.v00, v01 = V.v01, v02 = V.v02, v03 = V.v03, v11 = V.v11, v12 = V.v12, v13 = V.v13;
+  const double v22 = V.v22, v23 = V.v23, v33 = V.v33;
 
-    // Q_x = l_x + fx V_x ; Q_u = l_u + fu V_x (:149-150)
-    const double qx0 = c.lx0 + x0;
-    const double qx1 = c.lx1 + x1;
-    const double qx2 = c.lx2 + (al * x0 + be * x1 + x2);
-    const double qx3 = ga * x0 + de * x1 + x3;
-    const double qu0 = c.lu0 + (p * x0 + q * x1 + dt * x2);
-    const double qu1 = c.lu1 + dt * x3;
+  // Q_x = l_x + fx V_x ; Q_u = l_u + fu V_x (:149-150)
+  const double qx0 = c.lx0 + x0;
+  const double qx1 = c.lx1 + x1;
+  const double qx2 = fma(al, x0, fma(be, x1, x2 + c.lx2));
+  const double qx3 = fma(ga, x0, fma(de, x1, x3));
+  const double qu0 = fma(p, x0, fma(q, x1, fma(dt, x2, c.lu0)));
+  const double qu1 = fma(dt, x3, c.lu1);
 
-    // T = fx V (rows 2, 3) ; Q_xx = l_xx + T fx' (:151)
-    const double t20 = al * v00 + be * v01 + v02;
-    const double t21 = al * v01 + be * v11 + v12;
-    const double t22 = al * v02 + be * v12 + v22;
-    const double t23 = al * v03 + be * v13 + v23;
-    const double t30 = ga * v00 + de * v01 + v03;
-    const double t31 = ga * v01 + de * v11 + v13;
-    const double t32 = ga * v02 + de * v12 + v23;
-    const double t33 = ga * v03 + de * v13 + v33;
-    const double q00 = v00 + c.l00, q01 = v01 + c.l01, q11 = v11 + c.l11;
-    const double q02 = t20, q12 = t21, q03 = t30, q13 = t31;
-    const double q22 = (al * t20 + be * t21 + t22) + kp.w_vel * 2;
-    const double q23 = ga * t20 + de * t21 + t23;
-    const double q33 = ga * t30 + de * t31 + t33;
-    (void)t32;
+  // T = fx V (rows 2, 3) ; Q_xx = l_xx + T fx' (:151)
+  const double t20 = fma(al, v00, fma(be, v01, v02));
+  const double t21 = fma(al, v01, fma(be, v11, v12));
+  const double t22 = fma(al, v02, fma(be, v12, v22));
+  const double t23 = fma(al, v03, fma(be, v13, v23));
+  const double t30 = fma(ga, v00, fma(de, v01, v03));
+  const double t31 = fma(ga, v01, fma(de, v11, v13));
+  const double t33 = fma(ga, v03, fma(de, v13, v33));
+  const double q00 = v00 + c.l00, q01 = v01 + c.l01, q11 = v11 + c.l11;
+  const double q22 = fma(al, t20, fma(be, t21, t22 + two_wvel));
+  const double q23 = fma(ga, t20, fma(de, t21, t23));
+  const double q33 = fma(ga, t30, fma(de, t31, t33));
 
-    // E = fu V ; Q_ux = E fx' ; Q_uu = l_uu + E fu' (:152-153)
-    const double e00 = p * v00 + q * v01 + dt * v02;
-    const double e01 = p * v01 + q * v11 + dt * v12;
-    const double e02 = p * v02 + q * v12 + dt * v22;
-    const double e03 = p * v03 + q * v13 + dt * v23;
-    const double e10 = dt * v03, e11 = dt * v13, e12 = dt * v23, e13 = dt * v33;
-    const double ux00 = e00, ux01 = e01;
-    const double ux02 = al * e00 + be * e01 + e02;
-    const double ux03 = ga * e00 + de * e01 + e03;
-    const double ux10 = e10, ux11 = e11;
-    const double ux12 = al * e10 + be * e11 + e12;
-    const double ux13 = ga * e10 + de * e11 + e13;
-    const double a = (p * e00 + q * e01 + dt * e02) + c.luu0;
-    const double b = dt * e03;
-    const double d = dt * e13 + c.luu1;
-    if (!(a == a) || !(b == b) || !(d == d)) { ok = false; break; }
+  // E = fu V ; Q_ux = E fx' ; Q_uu = l_uu + E fu' (:152-153)
+  const double e00 = fma(p, v00, fma(q, v01, dt * v02));
+  const double e01 = fma(p, v01, fma(q, v11, dt * v12));
+  const double e02 = fma(p, v02, fma(q, v12, dt * v22));
+  const double e03 = fma(p, v03, fma(q, v13, dt * v23));
+  const double e10 = dt * v03, e11 = dt * v13, e12 = dt * v23, e13 = dt * v33;
+  const double ux02 = fma(al, e00, fma(be, e01, e02));
+  const double ux03 = fma(ga, e00, fma(de, e01, e03));
+  const double ux12 = fma(al, e10, fma(be, e11, e12));
+  const double ux13 = fma(ga, e10, fma(de, e11, e13));
+  const double a = fma(p, e00, fma(q, e01, fma(dt, e02, c.luu0)));
+  const double b = dt * e03;
+  const double d = fma(dt, e13, c.luu1);
 
-    // Regularised inverse V diag(1/(max(eig,0)+lamb)) V' (:155-175).  Positive semi-definite Q_uu (always, when l_xx
-    // and l_uu are: barrier Hessians are rank-one PSD): both eigenvalues pass the clamp and the result is
-    // inv(Q_uu + lamb I), formed from the adjugate with a single division.  Otherwise the clamped eigen form:
-    // with h = (a-d)/2, r = sqrt(h²+b²): inverse = (d1+d2)/2·I + (d1-d2)/2·[[h,b],[b,-h]]/r.
-    double i00, i01, i11;
-    if (a * d - b * b >= 0.0 && a + d >= 0.0) {
-      const double ar = a + lamb, dr = d + lamb;
-      const double rdet = 1.0 / (ar * dr - b * b);
-      i00 = dr * rdet;
-      i11 = ar * rdet;
-      i01 = -b * rdet;
-    } else {
-      const double mm = 0.5 * (a + d), h = 0.5 * (a - d);
-      const double rad = sqrt(h * h + b * b);
-      const double d1 = 1.0 / (fmax(mm + rad, 0.0) + lamb), d2 = 1.0 / (fmax(mm - rad, 0.0) + lamb);
-      const double hs = 0.5 * (d1 + d2), hd = 0.5 * (d1 - d2);
-      double c2 = 1.0, s2 = 0.0;
-      if (rad > 0.0) { c2 = h / rad; s2 = b / rad; }
-      i00 = hs + hd * c2;
-      i11 = hs - hd * c2;
-      i01 = hd * s2;
-    }
-
-    // k = -Qinv Q_u ; K = -Qinv Q_ux (:177-178)
-    const double k0 = -(i00 * qu0 + i01 * qu1);
-    const double k1 = -(i01 * qu0 + i11 * qu1);
-    const double K00 = -(i00 * ux00 + i01 * ux10), K01 = -(i00 * ux01 + i01 * ux11);
-    const double K02 = -(i00 * ux02 + i01 * ux12), K03 = -(i00 * ux03 + i01 * ux13);
-    const double K10 = -(i01 * ux00 + i11 * ux10), K11 = -(i01 * ux01 + i11 * ux11);
-    const double K12 = -(i01 * ux02 + i11 * ux12), K13 = -(i01 * ux03 + i11 * ux13);
-
-    // G = K' Q_uu (unregularised) ; V_x = Q_x - G k ; V_xx = Q_xx - G K (:180-181)
-    const double g00 = K00 * a + K10 * b, g01 = K00 * b + K10 * d;
-    const double g10 = K01 * a + K11 * b, g11 = K01 * b + K11 * d;
-    const double g20 = K02 * a + K12 * b, g21 = K02 * b + K12 * d;
-    const double g30 = K03 * a + K13 * b, g31 = K03 * b + K13 * d;
-    x0 = qx0 - (g00 * k0 + g01 * k1);
-    x1 = qx1 - (g10 * k0 + g11 * k1);
-    x2 = qx2 - (g20 * k0 + g21 * k1);
-    x3 = qx3 - (g30 * k0 + g31 * k1);
-    v00 = q00 - (g00 * K00 + g01 * K10);
-    v01 = q01 - (g00 * K01 + g01 * K11);
-    v02 = q02 - (g00 * K02 + g01 * K12);
-    v03 = q03 - (g00 * K03 + g01 * K13);
-    v11 = q11 - (g10 * K01 + g11 * K11);
-    v12 = q12 - (g10 * K02 + g11 * K12);
-    v13 = q13 - (g10 * K03 + g11 * K13);
-    v22 = q22 - (g20 * K02 + g21 * K12);
-    v23 = q23 - (g20 * K03 + g21 * K13);
-    v33 = q33 - (g30 * K03 + g31 * K13);
-
-    if (lane == 0) {
-      double* o = kK + j * KR;
-      o[0] = k0; o[1] = k1;
-      o[2] = K00; o[3] = K01; o[4] = K02; o[5] = K03;
-      o[6] = K10; o[7] = K11; o[8] = K12; o[9] = K13;
-    }
-    c = nx;
+  // Regularised inverse V diag(1/(max(eig,0)+lamb)) V' (:155-175).  Positive semi-definite Q_uu (always, when l_xx
+  // and l_uu are: barrier Hessians are rank-one PSD): both eigenvalues pass the clamp and the result is
+  // inv(Q_uu + lamb I), formed from the adjugate with one reciprocal.  Otherwise the clamped eigen form:
+  // with h = (a-d)/2, r = sqrt(h²+b²): inverse = (d1+d2)/2·I + (d1-d2)/2·[[h,b],[b,-h]]/r.
+  const double bb = b * b;
+  const double det0 = fma(a, d, -bb);
+  double i00, i01, i11;
+  if (FAST) suspect |= __builtin_amdgcn_ballot_w64(!(det0 >= 0.0)) | __builtin_amdgcn_ballot_w64(!(a + d >= 0.0));
+  if (FAST || (det0 >= 0.0 && a + d >= 0.0)) {
+    const double ar = a + lamb, dr = d + lamb;
+    const double rdet = rcp_newton(fma(ar, dr, -bb));
+    i00 = dr * rdet;
+    i11 = ar * rdet;
+    i01 = -b * rdet;
+  } else {
+    if (!(det0 == det0)) return false;  // NaN anywhere in Q_uu
+    const double mm = 0.5 * (a + d), h = 0.5 * (a - d);
+    const double rad = sqrt(fma(h, h, bb));
+    const double d1 = 1.0 / (fmax(mm + rad, 0.0) + lamb), d2 = 1.0 / (fmax(mm - rad, 0.0) + lamb);
+    const double hs = 0.5 * (d1 + d2), hd = 0.5 * (d1 - d2);
+    double c2 = 1.0, s2 = 0.0;
+    if (rad > 0.0) { c2 = h / rad; s2 = b / rad; }
+    i00 = fma(hd, c2, hs);
+    i11 = fma(-hd, c2, hs);
+    i01 = hd * s2;
   }
-  return ok;
+
+  // k = -Qinv Q_u ; K = -Qinv Q_ux (:177-178)
+  const double k0 = fma(-i00, qu0, -(i01 * qu1));
+  const double k1 = fma(-i01, qu0, -(i11 * qu1));
+  const double K00 = fma(-i00, e00, -(i01 * e10)), K01 = fma(-i00, e01, -(i01 * e11));
+  const double K02 = fma(-i00, ux02, -(i01 * ux12)), K03 = fma(-i00, ux03, -(i01 * ux13));
+  const double K10 = fma(-i01, e00, -(i11 * e10)), K11 = fma(-i01, e01, -(i11 * e11));
+  const double K12 = fma(-i01, ux02, -(i11 * ux12)), K13 = fma(-i01, ux03, -(i11 * ux13));
+
+  // G = K' Q_uu (unregularised) ; V_x = Q_x - G k ; V_xx = Q_xx - G K (:180-181)
+  const double g00 = fma(K00, a, K10 * b), g01 = fma(K00, b, K10 * d);
+  const double g10 = fma(K01, a, K11 * b), g11 = fma(K01, b, K11 * d);
+  const double g20 = fma(K02, a, K12 * b), g21 = fma(K02, b, K12 * d);
+  const double g30 = fma(K03, a, K13 * b), g31 = fma(K03, b, K13 * d);
+  V.x0 = fma(-g01, k1, fma(-g00, k0, qx0));
+  V.x1 = fma(-g11, k1, fma(-g10, k0, qx1));
+  V.x2 = fma(-g21, k1, fma(-g20, k0, qx2));
+  V.x3 = fma(-g31, k1, fma(-g30, k0, qx3));
+  V.v00 = fma(-g01, K10, fma(-g00, K00, q00));
+  V.v01 = fma(-g01, K11, fma(-g00, K01, q01));
+  V.v02 = fma(-g01, K12, fma(-g00, K02, t20));
+  V.v03 = fma(-g01, K13, fma(-g00, K03, t30));
+  V.v11 = fma(-g11, K11, fma(-g10, K01, q11));
+  V.v12 = fma(-g11, K12, fma(-g10, K02, t21));
+  V.v13 = fma(-g11, K13, fma(-g10, K03, t31));
+  V.v22 = fma(-g21, K12, fma(-g20, K02, q22));
+  V.v23 = fma(-g21, K13, fma(-g20, K03, q23));
+  V.v33 = fma(-g31, K13, fma(-g30, K03, q33));
+
+  if (threadIdx.x == 0) {  // every lane holds the same values; one lane stores (same-address stores from 64 lanes serialise)
+    out[0] = k0; out[1] = k1;
+    out[2] = K00; out[3] = K01; out[4] = K02; out[5] = K03;
+    out[6] = K10; out[7] = K11; out[8] = K12; out[9] = K13;
+  }
+  return true;
 }
 
-// Phase F: iLQR::forward_pass (I/iLQR.cpp:68-86).  All lanes compute the same values; lane 0 stores.  The operands of
-// step i+1 (old state, old control, gains) are read while step i computes.
+// Phase R: iLQR::backward_pass recursion (I/iLQR.cpp:108-191).  All lanes compute the same values; operands are
+// broadcast LDS reads issued one step ahead into the register set the next step uses (two steps per trip, no copies).
+template <bool FAST>
+__device__ __forceinline__ bool riccati_pass(const KParams& kp, int N, const double* rec, double* kK, double lamb_in,
+                                             unsigned long long& suspect) {
+  double dt = kp.dt, two_wvel = kp.w_vel * 2, lamb = lamb_in;
+  CILQR_PIN(dt); CILQR_PIN(two_wvel); CILQR_PIN(lamb);
+  Rec ra, rb;
+  load_rec(ra, rec, N - 1);
+  Value V;  // :108-113: terminal value = stage N-1
+  V.x0 = ra.lx0; V.x1 = ra.lx1; V.x2 = ra.lx2; V.x3 = 0.0;
+  V.v00 = ra.l00; V.v01 = ra.l01; V.v02 = 0.0; V.v03 = 0.0; V.v11 = ra.l11; V.v12 = 0.0; V.v13 = 0.0;
+  V.v22 = two_wvel; V.v23 = 0.0; V.v33 = 0.0;
+  int j = N - 1;
+  for (; j >= 1; j -= 2) {
+    load_rec(rb, rec, j - 1);
+    if (!riccati_step<FAST>(ra, V, dt, two_wvel, lamb, kK + j * KR, suspect)) return false;
+    load_rec(ra, rec, j >= 2 ? j - 2 : 0);
+    if (!riccati_step<FAST>(rb, V, dt, two_wvel, lamb, kK + (j - 1) * KR, suspect)) return false;
+  }
+  if (j == 0 && !riccati_step<FAST>(ra, V, dt, two_wvel, lamb, kK, suspect)) return false;
+  return true;
+}
+
+__device__ __noinline__ bool riccati_general(const KParams& kp, int N, const double* rec, double* kK, double lamb) {
+  unsigned long long unused = 0;
+  return riccati_pass<false>(kp, N, rec, kK, lamb, unused);
+}
+
+__device__ __forceinline__ bool riccati(const KParams& kp, int N, const double* rec, double* kK, double lamb) {
+  unsigned long long suspect = 0;
+  riccati_pass<true>(kp, N, rec, kK, lamb, suspect);
+  if (__builtin_expect(suspect != 0, 0)) return riccati_general(kp, N, rec, kK, lamb);
+  return true;
+}
+
+// ---- forward pass ---------------------------------------------------------------------------------------------------
+struct FwdConst {  // loop invariants of the forward pass, pinned in vector registers
+  double dt, half_dt2, acc_max, acc_min, yaw_hi, yaw_lo, speed_max, zero;
+  double two_over_pi, p1, p2, p3, s1, s2, s3, s4, s5, s6, c1, c2, c3, c4, c5, c6;
+};
+__device__ __forceinline__ void make_fwd_const(FwdConst& k, const KParams& kp) {
+  k.dt = kp.dt; k.half_dt2 = kp.half_dt2; k.acc_max = kp.acc_max; k.acc_min = kp.acc_min;
+  k.yaw_hi = kp.yaw_hi; k.yaw_lo = kp.yaw_lo; k.speed_max = kp.speed_max; k.zero = 0.0;
+  k.two_over_pi = 6.36619772367581382433e-01;
+  k.p1 = 1.57079632679489655800e+00; k.p2 = 6.12323399573676603587e-17; k.p3 = -1.49738490485916983278e-33;
+  k.s1 = -1.66666666666666324348e-01; k.s2 = 8.33333333332248946124e-03; k.s3 = -1.98412698298579493134e-04;
+  k.s4 = 2.75573137070700676789e-06; k.s5 = -2.50507602534068634195e-08; k.s6 = 1.58969099521155010221e-10;
+  k.c1 = 4.16666666666666019037e-02; k.c2 = -1.38888888888741095749e-03; k.c3 = 2.48015872894767294178e-05;
+  k.c4 = -2.75573143513906633035e-07; k.c5 = 2.08757232129817482790e-09; k.c6 = -1.13596475577881948265e-11;
+  CILQR_PIN(k.dt); CILQR_PIN(k.half_dt2); CILQR_PIN(k.acc_max); CILQR_PIN(k.acc_min); CILQR_PIN(k.yaw_hi);
+  CILQR_PIN(k.yaw_lo); CILQR_PIN(k.speed_max); CILQR_PIN(k.zero); CILQR_PIN(k.two_over_pi);
+  CILQR_PIN(k.p1); CILQR_PIN(k.p2); CILQR_PIN(k.p3);
+  CILQR_PIN(k.s1); CILQR_PIN(k.s2); CILQR_PIN(k.s3); CILQR_PIN(k.s4); CILQR_PIN(k.s5); CILQR_PIN(k.s6);
+  CILQR_PIN(k.c1); CILQR_PIN(k.c2); CILQR_PIN(k.c3); CILQR_PIN(k.c4); CILQR_PIN(k.c5); CILQR_PIN(k.c6);
+}
+
+// sincos_fast without its range guard and with every constant in a register (same arithmetic, same results for
+// |x| < 1e6; the caller tracks max|x| and redoes the pass on the guarded path if that bound was ever exceeded).
+__device__ __forceinline__ void sincos_loop(const FwdConst& k, double x, double& sn, double& cs) {
+  const double n = rint(x * k.two_over_pi);
+  double r = fma(-n, k.p1, x);
+  r = fma(-n, k.p2, r);
+  r = fma(-n, k.p3, r);
+  const double z = r * r;
+  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, k.s6, k.s5), k.s4), k.s3), k.s2), k.s1);
+  const double sr = fma(z * r, ps, r);
+  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, k.c6, k.c5), k.c4), k.c3), k.c2), k.c1);
+  const double hz = 0.5 * z;
+  const double w = 1.0 - hz;
+  const double cr = w + (((1.0 - w) - hz) + z * (z * pc));
+  const int q = (int)n;
+  const bool odd = (q & 1) != 0;
+  const double s0 = odd ? cr : sr;
+  const double c0 = odd ? sr : cr;
+  // sign flips as integer xors on the high words
+  const int sgs = (q & 2) << 30, sgc = ((q + 1) & 2) << 30;
+  sn = __hiloint2double(__double2hiint(s0) ^ sgs, __double2loint(s0));
+  cs = __hiloint2double(__double2hiint(c0) ^ sgc, __double2loint(c0));
+}
+
 struct FwdIn {
   double x, y, v, th, u0, u1, g[KR];
 };
-__device__ __forceinline__ FwdIn load_fwd(const double* X, const double* U, const double* kK, int i) {
-  FwdIn o;
+__device__ __forceinline__ void load_fwd(FwdIn& o, const double* X, const double* U, const double* kK, int i) {
   const double* xo = X + i * XR;
   o.x = xo[0]; o.y = xo[1]; o.v = xo[2]; o.th = xo[3];
   o.u0 = U[2 * i]; o.u1 = U[2 * i + 1];
   const double* g = kK + i * KR;
 #pragma unroll
   for (int k = 0; k < KR; ++k) o.g[k] = g[k];
-  return o;
 }
 
-__device__ __forceinline__ void forward(const KParams& kp, int N, int lane, const double* X, const double* U,
-                                        const double* kK, double* Xn, double* Un) {
+// One step of iLQR::forward_pass (I/iLQR.cpp:77-85) with Model::forward_simulate (I/Model.cpp:17-30) inlined.
+__device__ __forceinline__ void forward_step(const FwdConst& k, const FwdIn& c, State& s, double& max_th, double* Un_i,
+                                             double* Xn_next) {
+  const double d0 = s.x - c.x, d1 = s.y - c.y, d2 = s.v - c.v, d3 = s.th - c.th;
+  const double u0 = fma(c.g[5], d3, fma(c.g[4], d2, fma(c.g[3], d1, fma(c.g[2], d0, c.u0 + c.g[0]))));
+  const double u1 = fma(c.g[9], d3, fma(c.g[8], d2, fma(c.g[7], d1, fma(c.g[6], d0, c.u1 + c.g[1]))));
+  const double a = vmax(vmin(u0, k.acc_max), k.acc_min);
+  const double w = vmax(vmin(u1, s.v * k.yaw_hi), s.v * k.yaw_lo);
+  const double adv = fma(a, k.half_dt2, s.v * k.dt);
+  s.x = fma(s.c, adv, s.x);
+  s.y = fma(s.s, adv, s.y);
+  s.v = vmin(vmax(fma(a, k.dt, s.v), k.zero), k.speed_max);
+  s.th = fma(w, k.dt, s.th);
+  max_th = vmax(max_th, fabs(s.th));
+  sincos_loop(k, s.th, s.s, s.c);
+  if (threadIdx.x == 0) {
+    Un_i[0] = u0; Un_i[1] = u1;
+    Xn_next[0] = s.x; Xn_next[1] = s.y; Xn_next[2] = s.v; Xn_next[3] = s.th; Xn_next[4] = s.c; Xn_next[5] = s.s;
+  }
+}
+
+// Guarded (library-range sincos) form of the same pass; only reached if a heading ever exceeded 1e6 rad.
+__device__ __noinline__ void forward_guarded(const KParams& kp, int N, const double* X, const double* U, const double* kK,
+                                             double* Xn, double* Un) {
   State s;
   s.x = X[0]; s.y = X[1]; s.v = X[2]; s.th = X[3]; s.c = X[4]; s.s = X[5];
-  if (lane == 0) store_state(Xn, 0, s);
-  FwdIn c = load_fwd(X, U, kK, 0);
+  store_state(Xn, 0, s);
   for (int i = 0; i < N; ++i) {
-    const FwdIn nx = load_fwd(X, U, kK, i + 1 < N ? i + 1 : i);
-    const double d0 = s.x - c.x, d1 = s.y - c.y, d2 = s.v - c.v, d3 = s.th - c.th;
-    const double u0 = c.u0 + c.g[0] + (c.g[2] * d0 + c.g[3] * d1 + c.g[4] * d2 + c.g[5] * d3);
-    const double u1 = c.u1 + c.g[1] + (c.g[6] * d0 + c.g[7] * d1 + c.g[8] * d2 + c.g[9] * d3);
+    const double* xo = X + i * XR;
+    const double* g = kK + i * KR;
+    const double d0 = s.x - xo[0], d1 = s.y - xo[1], d2 = s.v - xo[2], d3 = s.th - xo[3];
+    const double u0 = fma(g[5], d3, fma(g[4], d2, fma(g[3], d1, fma(g[2], d0, U[2 * i] + g[0]))));
+    const double u1 = fma(g[9], d3, fma(g[8], d2, fma(g[7], d1, fma(g[6], d0, U[2 * i + 1] + g[1]))));
     s = dyn_step(kp, s, u0, u1);
-    if (lane == 0) {
-      Un[2 * i] = u0;
-      Un[2 * i + 1] = u1;
-      store_state(Xn, i + 1, s);
-    }
-    c = nx;
+    Un[2 * i] = u0;
+    Un[2 * i + 1] = u1;
+    store_state(Xn, i + 1, s);
   }
+}
+
+// Phase F: iLQR::forward_pass (I/iLQR.cpp:68-86).  All lanes compute and store the same values; the operands of step
+// i+1 (old state, old control, gains) are read while step i computes (two steps per trip, no register copies).
+__device__ __forceinline__ void forward(const KParams& kp, int N, const double* X, const double* U, const double* kK,
+                                        double* Xn, double* Un) {
+  FwdConst k;
+  make_fwd_const(k, kp);
+  State s;
+  s.x = X[0]; s.y = X[1]; s.v = X[2]; s.th = X[3]; s.c = X[4]; s.s = X[5];
+  store_state(Xn, 0, s);
+  double max_th = fabs(s.th);
+  FwdIn fa, fb;
+  load_fwd(fa, X, U, kK, 0);
+  int i = 0;
+  for (; i + 1 < N; i += 2) {
+    load_fwd(fb, X, U, kK, i + 1);
+    forward_step(k, fa, s, max_th, Un + 2 * i, Xn + (i + 1) * XR);
+    load_fwd(fa, X, U, kK, i + 2 < N ? i + 2 : i + 1);
+    forward_step(k, fb, s, max_th, Un + 2 * (i + 1), Xn + (i + 2) * XR);
+  }
+  if (i < N) forward_step(k, fa, s, max_th, Un + 2 * i, Xn + (i + 1) * XR);
+  if (__builtin_expect(!(max_th < 1.0e6), 0)) forward_guarded(kp, N, X, U, kK, Xn, Un);
 }
 
 // DIAG: per-solve shader-clock totals by phase, written to a.diag[b][8] = {prologue, L, R, F, epilogue, L count, R count,
@@ -546,11 +686,11 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
       }
       break;
     }
-    if (!riccati(kp, N, lane, rec, kK, lamb)) { status = CILQR_EXIT_NUMERIC; break; }
+    if (!riccati(kp, N, rec, kK, lamb)) { status = CILQR_EXIT_NUMERIC; break; }
     __syncthreads();
     CILQR_STAMP(c_R)
     if (DIAG) ++n_R;
-    forward(kp, N, lane, Xc, Uc, kK, Xn, Un);
+    forward(kp, N, Xc, Uc, kK, Xn, Un);
     __syncthreads();
     CILQR_STAMP(c_F)
     if (accept) {
