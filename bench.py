@@ -36,12 +36,91 @@ def algorithmic_bytes_per_solve(N, M):
     return 8 * (4 + 2 * N + 6 + 2 + 6 * M * N) + 8 * (2 * N + 4 * (N + 1) + 1) + 8
 
 
+def bench_warp(args, rank, local_rank, world, dist, dev):
+    """BASELINE config 4: 1024x1024 float32 occupancy map warped into a 1024x1024 vehicle-frame map, one frame per step,
+    source/destination resident in HBM, pose stream of scenes.make_c4 (theta 0→2π)."""
+    import cilqr_amd
+    from cilqr_amd import scenes
+    c4 = scenes.make_c4()
+    sg, dg = cilqr_amd.map_geom(*c4["src_geom"]), cilqr_amd.map_geom(*c4["dst_geom"])
+    solver = cilqr_amd.Solver(cilqr_amd.default_params(), max_batch=1, max_horizon=1, max_obstacles=0, device=local_rank)
+    src = torch.from_numpy(np.ascontiguousarray(c4["src"].T)).to(dev)  # column-major payload
+    dst = torch.zeros(dg.rows * dg.cols, dtype=torch.float32, device=dev)
+    oob = torch.zeros(1, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    poses = c4["poses"]
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(k, rec=False):
+        vx, vy, th = poses[(k + 7 * rank) % len(poses)]
+        if rec:
+            ev0[k].record()
+        solver.warp_costmap_device(stream, src.data_ptr(), sg, dst.data_ptr(), dg, vx, vy, th, 0, oob.data_ptr())
+        if rec:
+            ev1[k].record()
+    for k in range(args.warmup):
+        step(k)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k, True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    if rank == 0:
+        cells = dg.rows * dg.cols
+        bytes_launch = 8 * cells  # 4 B read + 4 B write per destination cell (SURVEY §8d)
+        achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
+        out = {"metric": "costmap warp frames/sec (1024x1024 -> 1024x1024)", "value": args.steps * world / elapsed, "unit": "frames/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 payload / f64 index math",
+               "data": "synthetic",
+               "config": {"workload": "BASELINE config 4: 1024x1024 occupancy costmap warp, one frame per step, maps resident in HBM"},
+               "roofline": {"bound": "hbm", "kernel": "warp_kernel (+ 8-byte counter memset)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms,
+                            "algorithmic_bytes_per_launch": bytes_launch}}
+        if not args.no_cpu_baseline:
+            from oracle import oracle as O
+            O.build(ref=False)
+            threads = O.max_threads()
+            osg, odg = O.map_geom(*c4["src_geom"]), O.map_geom(*c4["dst_geom"])
+            t1 = time.perf_counter()
+            nf = 20
+            for k in range(nf):
+                want, _ = O.warp(c4["src"], osg, odg, *poses[k], threads=threads)
+            cpu_s = time.perf_counter() - t1
+            solver.warp_costmap_device(stream, src.data_ptr(), sg, dst.data_ptr(), dg, *poses[nf - 1], 0, oob.data_ptr())
+            torch.cuda.synchronize()
+            got = dst.cpu().numpy().reshape(dg.cols, dg.rows).T
+            out["cpu_baseline"] = {"value": nf / cpu_s, "unit": "frames/s", "cores": threads, "kind": "port",
+                                   "sample": "the first %d frames of the pose stream, OpenMP over cells" % nf}
+            out["bit_exact_vs_oracle"] = bool(np.array_equal(got, want, equal_nan=True))
+        print(json.dumps(out), flush=True)
+    solver.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1024, help="solves per GPU per step (BASELINE config 2: 1024)")
+    ap.add_argument("--batch", type=int, default=0, help="solves per GPU per step (default: the config's own size)")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "warp"],
+                    help="c2 (default, the config BASELINE.json's metric is quoted on): B=1024 N=50 M=4; c3: B=4096 N=50, 8x32 "
+                         "sampled obstacles; c5: B=8192 per GPU N=80 M=16; warp: config 4, 1024x1024 costmap frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -63,16 +142,32 @@ def main():
     from cilqr_amd import scenes
     from cilqr_amd.dist import select_min_cost
 
-    B, N, M = args.batch, 50, 4
-    p = cilqr_amd.default_params(N)
-    sc = scenes.make_static(B, N, M, p, scenes.SEED0 + 2 + 1000 * rank)  # rank 0 == scenes.make_c2(B)
-    solver = cilqr_amd.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M, device=local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.workload == "warp":
+        return bench_warp(args, rank, local_rank, world, dist, dev)
+    if args.workload == "c2":
+        B, N, M = args.batch or 1024, 50, 4
+        p = cilqr_amd.default_params(N)
+        sc = scenes.make_static(B, N, M, p, scenes.SEED0 + 2 + 1000 * rank)  # rank 0 == scenes.make_c2(B)
+        wl = "BASELINE config 2: B=%d CILQR solves per GPU per step, N=50, M=4 static obstacles" % B
+    elif args.workload == "c5":
+        B, N, M = args.batch or 8192, 80, 16
+        p = cilqr_amd.default_params(N)
+        sc = scenes.make_c5(B, p, shard=rank)
+        wl = "BASELINE config 5 shard: B=%d CILQR solves per GPU per step, N=80, M=16 static obstacles" % B
+    else:
+        B, N = args.batch or 4096, 50
+        p = cilqr_amd.default_params(N)
+        sc = scenes.make_c3(B, p)
+        M = sc["M"]
+        wl = "BASELINE config 3: B=%d CILQR solves per GPU per step, N=50, 8 moving obstacles x 32 Gaussian samples (M=256, weight 1/32)" % B
+    solver = cilqr_amd.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M, device=local_rank)
 
     def dv(a, dtype=torch.float64):
         return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).to(dev)
     x0, U0, poly, xpl = dv(sc["x0"]), dv(sc["U"]), dv(sc["poly"]), dv(sc["xplan_fl"])
     pose, dim = dv(sc["obs_pose"]), dv(sc["obs_dim"])
+    wts = dv(sc["obs_weight"]) if sc["obs_weight"] is not None else None
     U = U0.clone()
     X = torch.zeros(B, 4 * (N + 1), dtype=torch.float64, device=dev)
     J = torch.zeros(B, dtype=torch.float64, device=dev)
@@ -88,7 +183,8 @@ def main():
         if k is not None:
             ev0[k].record()
         solver.solve_batch_device(stream, B, N, M, x0.data_ptr(), U.data_ptr(), poly.data_ptr(), xpl.data_ptr(), pose.data_ptr(),
-                                  dim.data_ptr(), 0, X.data_ptr(), J.data_ptr(), iters.data_ptr(), status.data_ptr())
+                                  dim.data_ptr(), wts.data_ptr() if wts is not None else 0, X.data_ptr(), J.data_ptr(),
+                                  iters.data_ptr(), status.data_ptr())
         if k is not None:
             ev1[k].record()
         solver.argmin_device(stream, B, J.data_ptr(), pair.data_ptr())
@@ -126,11 +222,10 @@ def main():
         # fp64 VALU work actually needed per solve: accepted iterations k = (iters - 5)/2 for λ-exits
         flops_solve = mean_iters * N * (6 * 200 + 100 * M + 800)
         out = {
-            "metric": "CILQR solves/sec (N=50, batch B)", "value": value, "unit": "solves/s", "n_gpus": world,
+            "metric": "CILQR solves/sec (N=%d, batch B)" % N, "value": value, "unit": "solves/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: B=%d CILQR solves per GPU per step, N=50, M=4 static obstacles, "
-                                   "inputs resident in HBM, + min-cost selection" % B,
+            "config": {"workload": wl + ", inputs resident in HBM, + min-cost selection",
                        "batch_per_gpu": B, "horizon": N, "obstacles": M, "mean_reference_iterations": mean_iters,
                        "parallelism": "scene-sharded x%d, RCCL all-gather of (J,index)" % world},
             "roofline": {"bound": "hbm", "kernel": "cilqr_solve_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -147,14 +242,17 @@ def main():
             threads = O.max_threads()
             po = O.default_params(N)
             t1 = time.perf_counter()
-            want = O.solve_batch(po, N, M, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"], None, threads=threads)
+            ns = min(B, 1024 if M <= 16 else 128)  # bounded sample: ≈10-30 s of CPU work
+            sl = lambda a: None if a is None else a[:ns]  # noqa: E731
+            want = O.solve_batch(po, N, M, sl(sc["x0"]), sl(sc["U"]), sl(sc["poly"]), sl(sc["xplan_fl"]), sl(sc["obs_pose"]),
+                                 sl(sc["obs_dim"]), sl(sc["obs_weight"]), threads=threads)
             cpu_s = time.perf_counter() - t1
-            du = float(np.max(np.abs(U.cpu().numpy() - want["U"])))
-            out["cpu_baseline"] = {"value": B / cpu_s, "unit": "solves/s", "cores": threads, "kind": "port",
-                                   "sample": "the same %d config-2 scenes, once, OpenMP over the batch" % B,
-                                   "per_core": B / cpu_s / threads}
+            du = float(np.max(np.abs(U.cpu().numpy()[:ns] - want["U"])))
+            out["cpu_baseline"] = {"value": ns / cpu_s, "unit": "solves/s", "cores": threads, "kind": "port",
+                                   "sample": "the first %d scenes of the same batch, once, OpenMP over the batch" % ns,
+                                   "per_core": ns / cpu_s / threads}
             out["max_abs_du_vs_oracle"] = du
-            out["iters_equal_oracle"] = bool(np.array_equal(iters.cpu().numpy(), want["iters"]))
+            out["iters_equal_oracle"] = bool(np.array_equal(iters.cpu().numpy()[:ns], want["iters"]))
         print(json.dumps(out), flush=True)
     solver.close()
     if dist is not None:
