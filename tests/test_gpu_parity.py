@@ -192,3 +192,33 @@ def test_warp_identity_and_bbox(cilqr, solver):
     assert np.all(got[100:200, 300:400] == 100.0) and got[0, 0] == src[0, 0]
     mask = bbox <= 90
     assert np.array_equal(got[mask], src[mask])
+
+
+# ------------------------------------------------------------------------------------------------ C++ façade
+def test_cpp_adapter_replays_reference_call_sequence(cilqr, oracle, tmp_path):
+    """host/ilqr_adapter.{h,cpp}: the reference node's own call sequence (set_global_plan → set_Obstacle →
+    clear_uncertainty_map → run_step, twice) in C++, through the C-ABI, on the SURVEY §8(c) scene."""
+    import json
+    import os
+    import subprocess
+    from conftest import PKG, ROOT
+    from cilqr_amd import scenes
+    exe = str(tmp_path / "adapter_replay")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "host"), "-o", exe,
+                    os.path.join(ROOT, "tests", "cpp", "adapter_replay.cpp"), "-L" + os.path.join(PKG, "lib"), "-lcilqr_hip",
+                    "-Wl,-rpath," + os.path.join(PKG, "lib")], check=True)
+    case = [c for c in load_golden("survey_known_answers.json")["cases"] if c["N"] == 50 and c["M"] == 4][0]
+    out = json.loads(subprocess.run([exe, "50", "4"], check=True, capture_output=True, text=True).stdout)
+    t0, t1 = out["ticks"]
+    assert t0["iterations"] == case["iterations"] and t0["exit"] == 1
+    assert np.max(np.abs(np.array(t0["U"][:2]) - np.array(case["U0"]))) < TIGHT
+    assert np.max(np.abs(np.array(t0["X"][-4:]) - np.array(case["XN"]))) < 1e-8
+    # second tick: warm start = first tick's U_result, same ego state (I/iLQR.cpp:253) — against the oracle
+    po = oracle.default_params(50)
+    sc = scenes.known_answer_scene(50, 4, po, local_plan=oracle.local_plan)
+    o0 = oracle.solve(po, 50, sc["x0"][0], sc["U"][0], sc["poly"][0], sc["xplan_fl"][0, 0], sc["xplan_fl"][0, 1], sc["obs_pose"][0], sc["obs_dim"][0])
+    o1 = oracle.solve(po, 50, sc["x0"][0], o0["U"], sc["poly"][0], sc["xplan_fl"][0, 0], sc["xplan_fl"][0, 1], sc["obs_pose"][0], sc["obs_dim"][0])
+    assert t1["iterations"] == o1["iters"] and t1["exit"] == o1["status"]
+    assert np.max(np.abs(np.array(t1["U"]) - o1["U"])) < 1e-8
+    assert t0["n_ref"] == 20
+    assert 0 <= out["best"] < 8 and np.isfinite(out["best_J"])
