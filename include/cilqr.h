@@ -188,6 +188,12 @@ int cilqr_argmin_device(cilqr_handle* h, void* stream, int B, const double* J, d
  * dev_buf[B][8] (device memory owned by the caller).  NULL restores the production kernel.  Never use it when timing. */
 int cilqr_set_diag_buffer(cilqr_handle* h, uint64_t* dev_buf);
 
+/* Test hook: runs the kernels' own regularised Q_uu inverse (I/iLQR.cpp:155-175) on n column-major 2×2 matrices (host
+ * buffers).  general = 0: the positive-semi-definite form of the production kernel; 1: the eigenvalue-clamping form of the
+ * GENERAL kernel (NaN rows where it reports a non-finite matrix).  Lets the rarely taken branch be checked against the
+ * reference's EigenSolver outputs (tests/golden/ref_quu.json) without having to provoke it through a whole solve. */
+int cilqr_debug_quu_inverse(cilqr_handle* h, int n, const double* Quu, const double* lamb, double* Qinv, int general);
+
 /* Blocks until everything the host-pointer entry points enqueued on the handle's own stream has finished. */
 int cilqr_wait(cilqr_handle* h);
 

@@ -20,7 +20,7 @@ EXIT_TOLERANCE, EXIT_LAMBDA_MAX, EXIT_MAX_ITER, EXIT_NUMERIC = 0, 1, 2, 3
 ABI_SYMBOLS = (
     "cilqr_params_default", "cilqr_abi_version", "cilqr_last_error", "cilqr_default_control_seq",
     "cilqr_local_plan", "cilqr_create", "cilqr_destroy", "cilqr_solve_batch", "cilqr_solve_batch_device",
-    "cilqr_argmin_device", "cilqr_wait", "cilqr_set_diag_buffer", "cilqr_warp_costmap", "cilqr_warp_costmap_device", "cilqr_map_geom_set",
+    "cilqr_argmin_device", "cilqr_wait", "cilqr_set_diag_buffer", "cilqr_debug_quu_inverse", "cilqr_warp_costmap", "cilqr_warp_costmap_device", "cilqr_map_geom_set",
 )
 
 _dp = C.POINTER(C.c_double)
@@ -178,6 +178,13 @@ class Solver:
 
     def set_diag_buffer(self, dev_ptr):
         _check(lib().cilqr_set_diag_buffer(self._h, _vp(dev_ptr)))
+
+    def debug_quu_inverse(self, Quu, lamb, general=True):
+        Quu = _np64(Quu).reshape(-1, 4)
+        lamb = _np64(lamb).reshape(-1)
+        out = np.zeros_like(Quu)
+        _check(lib().cilqr_debug_quu_inverse(self._h, int(Quu.shape[0]), _p(Quu), _p(lamb), _p(out), int(bool(general))))
+        return out
 
     def wait(self):
         _check(lib().cilqr_wait(self._h))

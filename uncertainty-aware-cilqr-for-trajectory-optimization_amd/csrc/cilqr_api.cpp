@@ -43,6 +43,7 @@ struct cilqr_handle {
   int32_t *d_iters, *d_status;
   // workspace
   double* d_obs_tab;
+  int32_t* d_redo;
   double* d_pair;
   // warp staging (grown on demand by the host-pointer warp entry point only)
   float *d_src, *d_dst, *d_bbox;
@@ -174,6 +175,7 @@ int cilqr_create(const cilqr_params* p, int max_batch, int max_horizon, int max_
   if (err == hipSuccess) err = dmalloc(&h->d_iters, B);
   if (err == hipSuccess) err = dmalloc(&h->d_status, B);
   if (err == hipSuccess) err = dmalloc(&h->d_obs_tab, B * M * N * 6);
+  if (err == hipSuccess) err = dmalloc(&h->d_redo, B);
   if (err == hipSuccess) err = dmalloc(&h->d_pair, (size_t)2);
   if (err == hipSuccess) err = dmalloc(&h->d_oob, (size_t)1);
   if (err != hipSuccess) {
@@ -190,7 +192,7 @@ int cilqr_destroy(cilqr_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->d_x0, h->d_U, h->d_poly, h->d_xplan, h->d_obs_pose, h->d_obs_dim, h->d_obs_w, h->d_X, h->d_J,
-                  h->d_iters, h->d_status, h->d_obs_tab, h->d_pair, h->d_src, h->d_dst, h->d_bbox, h->d_oob};
+                  h->d_iters, h->d_status, h->d_obs_tab, h->d_redo, h->d_pair, h->d_src, h->d_dst, h->d_bbox, h->d_oob};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -201,6 +203,22 @@ int cilqr_destroy(cilqr_handle* h) {
 int cilqr_set_diag_buffer(cilqr_handle* h, uint64_t* dev_buf) {
   if (!h) return fail(CILQR_ERR_ARG, "null handle");
   h->diag = (unsigned long long*)dev_buf;
+  return CILQR_OK;
+}
+
+int cilqr_debug_quu_inverse(cilqr_handle* h, int n, const double* Quu, const double* lamb, double* Qinv, int general) {
+  if (!h || n < 1 || !Quu || !lamb || !Qinv) return fail(CILQR_ERR_ARG, "cilqr_debug_quu_inverse: bad argument");
+  HIP_TRY(hipSetDevice(h->device));
+  double *dq = nullptr, *dl = nullptr, *dout = nullptr;
+  HIP_TRY(dmalloc(&dq, (size_t)4 * n));
+  HIP_TRY(dmalloc(&dl, (size_t)n));
+  HIP_TRY(dmalloc(&dout, (size_t)4 * n));
+  HIP_TRY(hipMemcpy(dq, Quu, sizeof(double) * 4 * n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dl, lamb, sizeof(double) * n, hipMemcpyHostToDevice));
+  HIP_TRY(cilqr::launch_quu_inverse(n, dq, dl, dout, general, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(Qinv, dout, sizeof(double) * 4 * n, hipMemcpyDeviceToHost));
+  (void)hipFree(dq); (void)hipFree(dl); (void)hipFree(dout);
   return CILQR_OK;
 }
 
@@ -224,6 +242,7 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
   a.obs_pose = obs_pose; a.obs_dim = obs_dim; a.obs_weight = M > 0 ? obs_weight : nullptr;
   a.X_out = X_out; a.J_out = J_out; a.iters_out = iters_out; a.status_out = status_out;
   a.obs_tab = h->d_obs_tab;
+  a.redo = h->d_redo;
   a.diag = h->diag;
   a.B = B; a.N = N; a.M = M; a.flags = flags;
   a.kp = h->kp;

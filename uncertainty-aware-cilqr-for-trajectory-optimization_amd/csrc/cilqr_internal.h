@@ -40,6 +40,7 @@ struct SolveArgs {
   int32_t* iters_out;   // may be null
   int32_t* status_out;  // may be null
   double* obs_tab;      // workspace: [B][M][6][N]
+  int32_t* redo;        // workspace: [B] hand-over flags from the fast kernel to the general kernel
   unsigned long long* diag;  // null, or [B][8] phase cycle totals (diagnostic instantiation)
   int32_t B, N, M;
   uint32_t flags;
@@ -49,6 +50,7 @@ struct SolveArgs {
 // Launchers (defined in the .hip files). All are asynchronous on `stream`.
 hipError_t launch_solve(const SolveArgs& a, hipStream_t stream);
 size_t solve_lds_bytes(int N, int n_samples);
+hipError_t launch_quu_inverse(int n, const double* q, const double* lamb, double* out, int general, hipStream_t stream);
 
 hipError_t launch_argmin(const double* J, int B, double* out_pair, double* scratch, hipStream_t stream);
 size_t argmin_scratch_doubles(int B);

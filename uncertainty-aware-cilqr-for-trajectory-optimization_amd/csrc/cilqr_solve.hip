@@ -279,6 +279,40 @@ __device__ __forceinline__ double rcp_newton(double x) {
   return r;
 }
 
+// Regularised inverse V diag(1/(max(eig,0)+lamb)) V' of the symmetric 2×2 [[a,b],[b,d]] (I/iLQR.cpp:155-175).
+// PSD case (always, when l_xx and l_uu are PSD: barrier Hessians are rank-one PSD): both eigenvalues pass the clamp and
+// the result is inv(Q_uu + lamb I), formed from the adjugate with one reciprocal.  bb = b².
+__device__ __forceinline__ void quu_inverse_psd(double a, double b, double d, double lamb, double bb, double& i00, double& i01,
+                                                double& i11) {
+  const double ar = a + lamb, dr = d + lamb;
+  const double rdet = rcp_newton(fma(ar, dr, -bb));
+  i00 = dr * rdet;
+  i11 = ar * rdet;
+  i01 = -b * rdet;
+}
+// General case.  With m = (a+d)/2, h = (a-d)/2, r = sqrt(h²+b²) the eigenvalues are m ± r and
+// inverse = (d1+d2)/2·I + (d1-d2)/2·[[h,b],[b,-h]]/r, d_i = 1/(max(eig_i,0)+lamb).  False for a non-finite matrix.
+__device__ __forceinline__ bool quu_inverse_general(double a, double b, double d, double lamb, double& i00, double& i01,
+                                                    double& i11) {
+  const double bb = b * b;
+  const double det0 = fma(a, d, -bb);
+  if (!(det0 == det0) || !(a + d == a + d)) return false;
+  if (det0 >= 0.0 && a + d >= 0.0) {
+    quu_inverse_psd(a, b, d, lamb, bb, i00, i01, i11);
+    return true;
+  }
+  const double mm = 0.5 * (a + d), h = 0.5 * (a - d);
+  const double rad = sqrt(fma(h, h, bb));
+  const double d1 = 1.0 / (fmax(mm + rad, 0.0) + lamb), d2 = 1.0 / (fmax(mm - rad, 0.0) + lamb);
+  const double hs = 0.5 * (d1 + d2), hd = 0.5 * (d1 - d2);
+  double c2 = 1.0, s2 = 0.0;
+  if (rad > 0.0) { c2 = h / rad; s2 = b / rad; }
+  i00 = fma(hd, c2, hs);
+  i11 = fma(-hd, c2, hs);
+  i01 = hd * s2;
+  return true;
+}
+
 // One per-step linearisation record held in registers.
 struct Rec {
   double lx0, lx1, lx2, l00, l01, l11, lu0, lu1, luu0, luu1, al, be, ga, de, p, q;
@@ -352,27 +386,14 @@ __device__ __forceinline__ bool riccati_step(const Rec& c, Value& V, double dt, 
   // and l_uu are: barrier Hessians are rank-one PSD): both eigenvalues pass the clamp and the result is
   // inv(Q_uu + lamb I), formed from the adjugate with one reciprocal.  Otherwise the clamped eigen form:
   // with h = (a-d)/2, r = sqrt(h²+b²): inverse = (d1+d2)/2·I + (d1-d2)/2·[[h,b],[b,-h]]/r.
-  const double bb = b * b;
-  const double det0 = fma(a, d, -bb);
   double i00, i01, i11;
-  if (FAST) suspect |= __builtin_amdgcn_ballot_w64(!(det0 >= 0.0)) | __builtin_amdgcn_ballot_w64(!(a + d >= 0.0));
-  if (FAST || (det0 >= 0.0 && a + d >= 0.0)) {
-    const double ar = a + lamb, dr = d + lamb;
-    const double rdet = rcp_newton(fma(ar, dr, -bb));
-    i00 = dr * rdet;
-    i11 = ar * rdet;
-    i01 = -b * rdet;
-  } else {
-    if (!(det0 == det0)) return false;  // NaN anywhere in Q_uu
-    const double mm = 0.5 * (a + d), h = 0.5 * (a - d);
-    const double rad = sqrt(fma(h, h, bb));
-    const double d1 = 1.0 / (fmax(mm + rad, 0.0) + lamb), d2 = 1.0 / (fmax(mm - rad, 0.0) + lamb);
-    const double hs = 0.5 * (d1 + d2), hd = 0.5 * (d1 - d2);
-    double c2 = 1.0, s2 = 0.0;
-    if (rad > 0.0) { c2 = h / rad; s2 = b / rad; }
-    i00 = fma(hd, c2, hs);
-    i11 = fma(-hd, c2, hs);
-    i01 = hd * s2;
+  if (FAST) {
+    const double bb = b * b;
+    const double det0 = fma(a, d, -bb);
+    suspect |= __builtin_amdgcn_ballot_w64(!(det0 >= 0.0)) | __builtin_amdgcn_ballot_w64(!(a + d >= 0.0));
+    quu_inverse_psd(a, b, d, lamb, bb, i00, i01, i11);
+  } else if (!quu_inverse_general(a, b, d, lamb, i00, i01, i11)) {
+    return false;
   }
 
   // k = -Qinv Q_u ; K = -Qinv Q_ux (:177-178)
@@ -435,16 +456,13 @@ __device__ __forceinline__ bool riccati_pass(const KParams& kp, int N, const dou
   return true;
 }
 
-__device__ __noinline__ bool riccati_general(const KParams& kp, int N, const double* rec, double* kK, double lamb) {
-  unsigned long long unused = 0;
-  return riccati_pass<false>(kp, N, rec, kK, lamb, unused);
-}
-
+// GENERAL = false: the branch-free fast pass; returns false when any step was suspect (the caller then hands the
+// solve to the GENERAL kernel).  GENERAL = true: the branching pass; returns false only for a non-finite Q_uu.
+template <bool GENERAL>
 __device__ __forceinline__ bool riccati(const KParams& kp, int N, const double* rec, double* kK, double lamb) {
   unsigned long long suspect = 0;
-  riccati_pass<true>(kp, N, rec, kK, lamb, suspect);
-  if (__builtin_expect(suspect != 0, 0)) return riccati_general(kp, N, rec, kK, lamb);
-  return true;
+  const bool ok = riccati_pass<!GENERAL>(kp, N, rec, kK, lamb, suspect);
+  return GENERAL ? ok : suspect == 0;
 }
 
 // ---- forward pass ---------------------------------------------------------------------------------------------------
@@ -525,34 +543,17 @@ __device__ __forceinline__ void forward_step(const FwdConst& k, const FwdIn& c, 
   }
 }
 
-// Guarded (library-range sincos) form of the same pass; only reached if a heading ever exceeded 1e6 rad.
-__device__ __noinline__ void forward_guarded(const KParams& kp, int N, const double* X, const double* U, const double* kK,
+// Phase F: iLQR::forward_pass (I/iLQR.cpp:68-86).  All lanes compute the same values; lane 0 stores; the operands of
+// step i+1 (old state, old control, gains) are read while step i computes (two steps per trip, no register copies).
+// Returns false if a heading left the range of the in-loop sincos (|theta| ≥ 1e6 rad, or NaN): the results are then not
+// to be used and the solve is handed to the GENERAL kernel.
+__device__ __forceinline__ bool forward_fast(const KParams& kp, int N, const double* X, const double* U, const double* kK,
                                              double* Xn, double* Un) {
-  State s;
-  s.x = X[0]; s.y = X[1]; s.v = X[2]; s.th = X[3]; s.c = X[4]; s.s = X[5];
-  store_state(Xn, 0, s);
-  for (int i = 0; i < N; ++i) {
-    const double* xo = X + i * XR;
-    const double* g = kK + i * KR;
-    const double d0 = s.x - xo[0], d1 = s.y - xo[1], d2 = s.v - xo[2], d3 = s.th - xo[3];
-    const double u0 = fma(g[5], d3, fma(g[4], d2, fma(g[3], d1, fma(g[2], d0, U[2 * i] + g[0]))));
-    const double u1 = fma(g[9], d3, fma(g[8], d2, fma(g[7], d1, fma(g[6], d0, U[2 * i + 1] + g[1]))));
-    s = dyn_step(kp, s, u0, u1);
-    Un[2 * i] = u0;
-    Un[2 * i + 1] = u1;
-    store_state(Xn, i + 1, s);
-  }
-}
-
-// Phase F: iLQR::forward_pass (I/iLQR.cpp:68-86).  All lanes compute and store the same values; the operands of step
-// i+1 (old state, old control, gains) are read while step i computes (two steps per trip, no register copies).
-__device__ __forceinline__ void forward(const KParams& kp, int N, const double* X, const double* U, const double* kK,
-                                        double* Xn, double* Un) {
   FwdConst k;
   make_fwd_const(k, kp);
   State s;
   s.x = X[0]; s.y = X[1]; s.v = X[2]; s.th = X[3]; s.c = X[4]; s.s = X[5];
-  store_state(Xn, 0, s);
+  if (threadIdx.x == 0) store_state(Xn, 0, s);
   double max_th = fabs(s.th);
   FwdIn fa, fb;
   load_fwd(fa, X, U, kK, 0);
@@ -564,14 +565,64 @@ __device__ __forceinline__ void forward(const KParams& kp, int N, const double* 
     forward_step(k, fb, s, max_th, Un + 2 * (i + 1), Xn + (i + 2) * XR);
   }
   if (i < N) forward_step(k, fa, s, max_th, Un + 2 * i, Xn + (i + 1) * XR);
-  if (__builtin_expect(!(max_th < 1.0e6), 0)) forward_guarded(kp, N, X, U, kK, Xn, Un);
+  return max_th < 1.0e6;
+}
+
+// The same pass with the range-guarded sincos (library path for huge arguments); GENERAL kernel only.
+__device__ __forceinline__ void forward_general(const KParams& kp, int N, const double* X, const double* U, const double* kK,
+                                                double* Xn, double* Un) {
+  State s;
+  s.x = X[0]; s.y = X[1]; s.v = X[2]; s.th = X[3]; s.c = X[4]; s.s = X[5];
+  if (threadIdx.x == 0) store_state(Xn, 0, s);
+  for (int i = 0; i < N; ++i) {
+    const double* xo = X + i * XR;
+    const double* g = kK + i * KR;
+    const double d0 = s.x - xo[0], d1 = s.y - xo[1], d2 = s.v - xo[2], d3 = s.th - xo[3];
+    const double u0 = fma(g[5], d3, fma(g[4], d2, fma(g[3], d1, fma(g[2], d0, U[2 * i] + g[0]))));
+    const double u1 = fma(g[9], d3, fma(g[8], d2, fma(g[7], d1, fma(g[6], d0, U[2 * i + 1] + g[1]))));
+    s = dyn_step(kp, s, u0, u1);
+    if (threadIdx.x == 0) {
+      Un[2 * i] = u0;
+      Un[2 * i + 1] = u1;
+      store_state(Xn, i + 1, s);
+    }
+  }
+}
+
+// Nominal rollout (I/iLQR.cpp:51-62) on the in-loop sincos; false ⇒ hand over to the GENERAL kernel.
+__device__ __forceinline__ bool rollout_fast(const KParams& kp, int N, const double* x0, const double* U, double* X) {
+  FwdConst k;
+  make_fwd_const(k, kp);
+  State s;
+  s.x = x0[0]; s.y = x0[1]; s.v = x0[2]; s.th = x0[3];
+  double max_th = fabs(s.th);
+  sincos_loop(k, s.th, s.s, s.c);
+  if (threadIdx.x == 0) store_state(X, 0, s);
+  for (int i = 0; i < N; ++i) {
+    const double u0 = U[2 * i], u1 = U[2 * i + 1];
+    const double a = vmax(vmin(u0, k.acc_max), k.acc_min);
+    const double w = vmax(vmin(u1, s.v * k.yaw_hi), s.v * k.yaw_lo);
+    const double adv = fma(a, k.half_dt2, s.v * k.dt);
+    s.x = fma(s.c, adv, s.x);
+    s.y = fma(s.s, adv, s.y);
+    s.v = vmin(vmax(fma(a, k.dt, s.v), k.zero), k.speed_max);
+    s.th = fma(w, k.dt, s.th);
+    max_th = vmax(max_th, fabs(s.th));
+    sincos_loop(k, s.th, s.s, s.c);
+    if (threadIdx.x == 0) store_state(X, i + 1, s);
+  }
+  return max_th < 1.0e6;
 }
 
 // DIAG: per-solve shader-clock totals by phase, written to a.diag[b][8] = {prologue, L, R, F, epilogue, L count, R count,
 // total}.  A separate instantiation so that the production kernel carries no stamps.
 // TABLDS: the obstacle table of the solve lives in LDS (chosen by the launcher when it fits beside the rest at the
 // wanted residency) instead of the global workspace.
-template <bool DIAG, bool TABLDS>
+// GENERAL: false = the production kernel: branch-free fast passes.  A solve that meets anything the fast passes do not
+// cover (Q_uu not positive semi-definite or not finite; a heading beyond the in-loop sincos range) stops WITHOUT touching
+// its outputs and sets a.redo[b]; the GENERAL = true kernel, launched right behind on the same stream, redoes exactly
+// those solves from their untouched inputs with the branching passes and returns at once for all others.
+template <bool DIAG, bool TABLDS, bool GENERAL>
 __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   unsigned long long tk0 = 0, tk = 0, c_pro = 0, c_L = 0, c_R = 0, c_F = 0, n_L = 0, n_R = 0;
   if (DIAG) tk0 = tk = __builtin_readcyclecounter();
@@ -584,9 +635,10 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
-  const KParams& kp = a.kp;
+  const KParams kp = a.kp;
   const int N = a.N, M = a.M, S = kp.n_samples;
   if (b >= a.B) return;
+  if (GENERAL && a.redo[b] == 0) return;
 
   double* samp = lds;
   double* Xa = samp + 2 * S;
@@ -641,7 +693,8 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   }
   __syncthreads();
 
-  {  // nominal rollout, I/iLQR.cpp:51-62
+  bool handover = false;  // fast kernel only: this solve needs the GENERAL kernel
+  if (GENERAL) {          // nominal rollout, I/iLQR.cpp:51-62
     const double* x0 = a.x0 + (size_t)b * 4;
     State s;
     s.x = x0[0]; s.y = x0[1]; s.v = x0[2]; s.th = x0[3];
@@ -651,6 +704,8 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
       s = dyn_step(kp, s, Ua[2 * i], Ua[2 * i + 1]);
       if (lane == 0) store_state(Xa, i + 1, s);
     }
+  } else {
+    handover = !rollout_fast(kp, N, a.x0 + (size_t)b * 4, Ua, Xa);
   }
   __syncthreads();
 
@@ -665,7 +720,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   bool j_valid = false;  // J_new is get_J of the current (Xc, Uc)
   const bool faithful = (a.flags & CILQR_FLAG_FAITHFUL_ITERS) != 0;
   const int max_it = kp.max_iterations;
-  for (int it = 0; it < max_it; ++it) {
+  for (int it = 0; it < max_it && !handover; ++it) {
     ++iters;
     // The reference evaluates backward_pass, forward_pass, then J_new = get_J(X, U) on the CURRENT X, U (:213-217).
     // The linearisation and J share their closest-point searches, so they are computed together, first.
@@ -676,7 +731,10 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
     if (DIAG) ++n_L;
     const bool accept = J_new < J_old;
     if (!accept && !faithful) {
-      // A rejection leaves X, U untouched, so every later iteration recomputes the same J_new == J_old and
+      // The reference runs backward_pass BEFORE this test (:213-215) and stops there if it fails.  With a NaN in the
+      // trajectory (the only way J_new is NaN) every Q_uu from that step down is NaN, i.e. that is the failing case.
+      if (J_new != J_new) { status = CILQR_EXIT_NUMERIC; break; }
+      // Otherwise a rejection leaves X, U untouched, so every later iteration recomputes the same J_new == J_old and
       // rejects again until lamb > lamb_max or the iteration cap: only lamb and the counter change.
       for (;;) {
         lamb = lamb * kp.lamb_factor;
@@ -686,11 +744,20 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
       }
       break;
     }
-    if (!riccati(kp, N, rec, kK, lamb)) { status = CILQR_EXIT_NUMERIC; break; }
+    if (!riccati<GENERAL>(kp, N, rec, kK, lamb)) {
+      if (GENERAL) { status = CILQR_EXIT_NUMERIC; break; }
+      handover = true;
+      break;
+    }
     __syncthreads();
     CILQR_STAMP(c_R)
     if (DIAG) ++n_R;
-    forward(kp, N, Xc, Uc, kK, Xn, Un);
+    if (GENERAL) {
+      forward_general(kp, N, Xc, Uc, kK, Xn, Un);
+    } else if (!forward_fast(kp, N, Xc, Uc, kK, Xn, Un)) {
+      handover = true;
+      break;
+    }
     __syncthreads();
     CILQR_STAMP(c_F)
     if (accept) {
@@ -706,7 +773,13 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
     J_old = J_new;
   }
 
+  if (!GENERAL) {
+    if (lane == 0) a.redo[b] = handover ? 1 : 0;
+    if (handover) return;  // outputs (and the in/out U) untouched: the GENERAL kernel starts from the same inputs
+  }
+
   // ---- epilogue: X_result / U_result (:243-244) ----------------------------------------------------------------
+  __syncthreads();
   for (int i = lane; i < 2 * N; i += WAVE) Ug[i] = Uc[i];
   double* Xg = a.X_out + (size_t)b * 4 * (N + 1);
   for (int i = lane; i < 4 * (N + 1); i += WAVE) Xg[i] = Xc[(i >> 2) * XR + (i & 3)];
@@ -733,6 +806,34 @@ size_t solve_lds_bytes(int N, int n_samples) {
   return doubles * sizeof(double);
 }
 
+namespace {
+template <bool DIAG, bool TABLDS>
+void launch_pair(const SolveArgs& a, size_t lds, hipStream_t stream) {
+  hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, TABLDS, false>), dim3(a.B), dim3(WAVE), lds, stream, a);
+  hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, TABLDS, true>), dim3(a.B), dim3(WAVE), lds, stream, a);
+}
+}  // namespace
+
+namespace {
+__global__ void quu_inverse_kernel(int n, const double* q, const double* lamb, double* out, int general) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double a = q[4 * i], b = 0.5 * (q[4 * i + 1] + q[4 * i + 2]), d = q[4 * i + 3];
+  double i00 = 0, i01 = 0, i11 = 0;
+  bool ok = true;
+  if (general) ok = quu_inverse_general(a, b, d, lamb[i], i00, i01, i11);
+  else quu_inverse_psd(a, b, d, lamb[i], b * b, i00, i01, i11);
+  const double nan = __builtin_nan("");
+  out[4 * i] = ok ? i00 : nan; out[4 * i + 1] = ok ? i01 : nan; out[4 * i + 2] = ok ? i01 : nan; out[4 * i + 3] = ok ? i11 : nan;
+}
+}  // namespace
+
+hipError_t launch_quu_inverse(int n, const double* q, const double* lamb, double* out, int general, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(quu_inverse_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, n, q, lamb, out, general);
+  return hipGetLastError();
+}
+
 hipError_t launch_solve(const SolveArgs& a, hipStream_t stream) {
   if (a.B <= 0) return hipSuccess;
   size_t lds = solve_lds_bytes(a.N, a.kp.n_samples);
@@ -741,11 +842,11 @@ hipError_t launch_solve(const SolveArgs& a, hipStream_t stream) {
   const bool tab_lds = a.M > 0 && lds + tab_bytes <= 32 * 1024;
   if (tab_lds) lds += tab_bytes;
   if (a.diag) {
-    if (tab_lds) hipLaunchKernelGGL((cilqr_solve_kernel<true, true>), dim3(a.B), dim3(WAVE), lds, stream, a);
-    else hipLaunchKernelGGL((cilqr_solve_kernel<true, false>), dim3(a.B), dim3(WAVE), lds, stream, a);
+    if (tab_lds) launch_pair<true, true>(a, lds, stream);
+    else launch_pair<true, false>(a, lds, stream);
   } else {
-    if (tab_lds) hipLaunchKernelGGL((cilqr_solve_kernel<false, true>), dim3(a.B), dim3(WAVE), lds, stream, a);
-    else hipLaunchKernelGGL((cilqr_solve_kernel<false, false>), dim3(a.B), dim3(WAVE), lds, stream, a);
+    if (tab_lds) launch_pair<false, true>(a, lds, stream);
+    else launch_pair<false, false>(a, lds, stream);
   }
   return hipGetLastError();
 }
