@@ -29,6 +29,52 @@ __global__ __launch_bounds__(64) void k(double* out, unsigned long long* cyc, do
 #pragma unroll
       for (int j = 0; j < 8; ++j) f = __builtin_fmaf(f, (float)b, (float)a);
       x0 = f;
+    } else if (MODE == 8) {  // VOP3 v_fma_f64 with three distinct VGPR sources and a distinct destination
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(x4) : "v"(x0), "v"(x1), "v"(x2));
+        asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(x5) : "v"(x1), "v"(x2), "v"(x3));
+        asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(x6) : "v"(x2), "v"(x3), "v"(x0));
+        asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(x7) : "v"(x3), "v"(x0), "v"(x1));
+      }
+    } else if (MODE == 9) {  // v_fmac_f64 (VOP2) all-VGPR
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(x4) : "v"(x0), "v"(x1));
+        asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(x5) : "v"(x1), "v"(x2));
+        asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(x6) : "v"(x2), "v"(x3));
+        asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(x7) : "v"(x3), "v"(x0));
+      }
+    } else if (MODE == 10) {  // v_mul_f64 all-VGPR
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        asm volatile("v_mul_f64 %0, %1, %2" : "=v"(x4) : "v"(x0), "v"(x1));
+        asm volatile("v_mul_f64 %0, %1, %2" : "=v"(x5) : "v"(x1), "v"(x2));
+        asm volatile("v_mul_f64 %0, %1, %2" : "=v"(x6) : "v"(x2), "v"(x3));
+        asm volatile("v_mul_f64 %0, %1, %2" : "=v"(x7) : "v"(x3), "v"(x0));
+      }
+    } else if (MODE == 11) {  // v_add_f64 all-VGPR
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        asm volatile("v_add_f64 %0, %1, %2" : "=v"(x4) : "v"(x0), "v"(x1));
+        asm volatile("v_add_f64 %0, %1, %2" : "=v"(x5) : "v"(x1), "v"(x2));
+        asm volatile("v_add_f64 %0, %1, %2" : "=v"(x6) : "v"(x2), "v"(x3));
+        asm volatile("v_add_f64 %0, %1, %2" : "=v"(x7) : "v"(x3), "v"(x0));
+      }
+    } else if (MODE == 12) {  // v_mov_b64 / s_mov / v_cndmask mix: 8 v_mov_b32
+#pragma unroll
+      for (int j = 0; j < 8; ++j) asm volatile("v_mov_b64 %0, %1" : "=v"(x4) : "v"(x0));
+    } else if (MODE == 13) {  // 8 s_mov_b32
+#pragma unroll
+      for (int j = 0; j < 8; ++j) asm volatile("s_mov_b32 s20, 0x3ff00000" ::: "s20");
+    } else if (MODE == 14) {  // 8 ds_read_b128 uniform address, then wait
+      __shared__ double buf[64];
+      double2 t0v;
+      int zero_addr = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(t0v) : "v"(zero_addr));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      x4 = t0v.x + buf[0];
     } else if (MODE == 7) {  // 4 interleaved chains
 #pragma unroll
       for (int j = 0; j < 2; ++j) { x0 = __builtin_fma(x0, b, a); x1 = __builtin_fma(x1, b, a); x2 = __builtin_fma(x2, b, a); x3 = __builtin_fma(x3, b, a); }
@@ -67,7 +113,7 @@ template <int MODE> void run(const char* name, int per_it, int blocks) {
   hipFree(out); hipFree(cyc);
 }
 int main() {
-  for (int blocks : {1, 1024, 2048, 4096}) {
+  for (int blocks : {1024, 2048}) {
     run<0>("dep fma x8", 8, blocks);
     run<1>("indep fma x8", 8, blocks);
     run<2>("2 chains", 8, blocks);
@@ -76,6 +122,13 @@ int main() {
     run<3>("dep div (+add)", 1, blocks);
     run<4>("dep sqrt (+add)", 1, blocks);
     run<6>("dep fma f32 x8", 8, blocks);
+    run<8>("v_fma_f64 VOP3 3xVGPR", 8, blocks);
+    run<9>("v_fmac_f64 VOP2", 8, blocks);
+    run<10>("v_mul_f64", 8, blocks);
+    run<11>("v_add_f64", 8, blocks);
+    run<12>("v_mov_b32", 8, blocks);
+    run<13>("s_mov_b32", 8, blocks);
+    run<14>("8x ds_read_b128 + wait", 8, blocks);
   }
   double* out; unsigned long long* cyc; hipMalloc(&out, 8 * 64); hipMalloc(&cyc, 8);
   lds_rt<<<1, 64>>>(out, cyc, 1.0); hipDeviceSynchronize();
