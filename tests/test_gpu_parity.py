@@ -279,3 +279,53 @@ def test_quu_inverse_branches_vs_reference_eigensolver(cilqr, solver):
     assert np.max(np.max(np.abs(fast - want[psd]), axis=1) / scale[psd] / np.maximum(cond, 1.0)) < 1e-14
     nan = solver.debug_quu_inverse(np.array([[1.0, np.nan, np.nan, 2.0], [np.inf, 0.0, 0.0, -np.inf]]), np.array([1.0, 1.0]), general=True)
     assert np.isnan(nan).all()
+
+
+# ------------------------------------------------------------------------------------------------ grouped kernel family
+@pytest.mark.parametrize("G", [1, 2, 4, 8, 16, 32])
+def test_grouped_kernels_match_oracle(cilqr, oracle, G):
+    """The G-lanes-per-solve kernel family (large batches; chosen automatically above B = 2048) forced onto small batches
+    through the CILQR_FORCE_G test hook: same parity bar as the wavefront-per-solve family, ragged batch sizes included."""
+    import os
+    from cilqr_amd import scenes
+    os.environ["CILQR_FORCE_G"] = str(G)
+    try:
+        s = cilqr.Solver(cilqr.default_params(), max_batch=300, max_horizon=80, max_obstacles=16, device=0)
+    finally:
+        del os.environ["CILQR_FORCE_G"]
+    try:
+        for N, M, B, seed in ((50, 4, 203, 301), (80, 16, 37, 302), (50, 0, 65, 303), (7, 2, 5, 304)):
+            sc = scenes.make_static(B, N, M, cilqr.default_params(N), seed)
+            _compare(_gpu_batch(s, sc), _oracle_batch(oracle, N, sc), TIGHT, "G%d N%d M%d" % (G, N, M))
+        # hand-over to the GENERAL instantiation (huge heading) and the NaN containment, as for the wavefront family
+        sc = scenes.make_c2(16, cilqr.default_params(50))
+        base = _gpu_batch(s, sc)
+        sa = dict(sc, x0=sc["x0"].copy())
+        sa["x0"][5, 3] += 2 * np.pi * 400000
+        _compare(_gpu_batch(s, sa), _oracle_batch(oracle, 50, sa), 1e-7, "G%d huge heading" % G)
+        sn = dict(sc, x0=sc["x0"].copy())
+        sn["x0"][3, 1] = np.nan
+        r = _gpu_batch(s, sn)
+        keep = np.arange(16) != 3
+        assert np.array_equal(r["U"][keep], base["U"][keep])
+        # sampled, weighted obstacles (config-3 shape)
+        sc3 = scenes.make_c3(24, cilqr.default_params(50), n_dyn=4, n_samples=4)
+        _compare(_gpu_batch(s, sc3), _oracle_batch(oracle, 50, sc3), TIGHT, "G%d C3" % G)
+    finally:
+        s.close()
+
+
+def test_automatic_family_choice_large_batch(cilqr, oracle):
+    """B = 4096 > 2048 takes the grouped family automatically (G = 16); a 256-solve sample is checked against the oracle."""
+    from cilqr_amd import scenes
+    p = cilqr.default_params(50)
+    sc = scenes.make_static(4096, 50, 4, p, 401)
+    s = cilqr.Solver(p, max_batch=4096, max_horizon=50, max_obstacles=4, device=0)
+    try:
+        got = _gpu_batch(s, sc)
+    finally:
+        s.close()
+    sub = {k: (v[:256] if isinstance(v, np.ndarray) else v) for k, v in sc.items()}
+    want = _oracle_batch(oracle, 50, sub)
+    _compare({k: v[:256] for k, v in got.items()}, want, TIGHT, "auto G")
+    assert np.isfinite(got["U"]).all()

@@ -3,6 +3,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -43,7 +44,9 @@ struct cilqr_handle {
   int32_t *d_iters, *d_status;
   // workspace
   double* d_obs_tab;
+  double* d_ws;      // workspace of the G-lanes-per-solve kernel family
   int32_t* d_redo;
+  int force_g;       // 0 = automatic; else 1,2,4,8,16,32 or 64 (test hook: environment CILQR_FORCE_G at create)
   double* d_pair;
   // warp staging (grown on demand by the host-pointer warp entry point only)
   float *d_src, *d_dst, *d_bbox;
@@ -161,6 +164,7 @@ int cilqr_create(const cilqr_params* p, int max_batch, int max_horizon, int max_
   derive(*p, h->kp);
   h->device = device;
   h->max_batch = max_batch; h->max_horizon = max_horizon; h->max_obstacles = max_obstacles;
+  if (const char* fg = getenv("CILQR_FORCE_G")) h->force_g = atoi(fg);
   const size_t B = max_batch, N = max_horizon, M = max_obstacles;
   hipError_t err = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (err == hipSuccess) err = dmalloc(&h->d_x0, B * 4);
@@ -174,7 +178,9 @@ int cilqr_create(const cilqr_params* p, int max_batch, int max_horizon, int max_
   if (err == hipSuccess) err = dmalloc(&h->d_J, B);
   if (err == hipSuccess) err = dmalloc(&h->d_iters, B);
   if (err == hipSuccess) err = dmalloc(&h->d_status, B);
-  if (err == hipSuccess) err = dmalloc(&h->d_obs_tab, B * M * N * 6);
+  const size_t Bpad = (B + 63) / 64 * 64;  // the grouped kernels pad the batch to whole wavefronts
+  if (err == hipSuccess) err = dmalloc(&h->d_obs_tab, Bpad * M * N * 6);
+  if (err == hipSuccess) err = dmalloc(&h->d_ws, cilqr::solve_groups_ws_doubles(max_batch, max_horizon));
   if (err == hipSuccess) err = dmalloc(&h->d_redo, B);
   if (err == hipSuccess) err = dmalloc(&h->d_pair, (size_t)2);
   if (err == hipSuccess) err = dmalloc(&h->d_oob, (size_t)1);
@@ -192,7 +198,7 @@ int cilqr_destroy(cilqr_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->d_x0, h->d_U, h->d_poly, h->d_xplan, h->d_obs_pose, h->d_obs_dim, h->d_obs_w, h->d_X, h->d_J,
-                  h->d_iters, h->d_status, h->d_obs_tab, h->d_redo, h->d_pair, h->d_src, h->d_dst, h->d_bbox, h->d_oob};
+                  h->d_iters, h->d_status, h->d_obs_tab, h->d_ws, h->d_redo, h->d_pair, h->d_src, h->d_dst, h->d_bbox, h->d_oob};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -247,7 +253,18 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
   a.B = B; a.N = N; a.M = M; a.flags = flags;
   a.kp = h->kp;
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(cilqr::launch_solve(a, (hipStream_t)stream));
+  // Kernel family by batch size: up to ≈2 solves per SIMD one wavefront per solve (LDS-resident); above,
+  // G lanes per solve with G the power of two nearest below 65536/B, i.e. about one wavefront per SIMD of the 1024.
+  int G = 64;
+  if (h->force_g == 1 || h->force_g == 2 || h->force_g == 4 || h->force_g == 8 || h->force_g == 16 || h->force_g == 32 || h->force_g == 64) {
+    G = h->force_g;
+  } else if (B > 2048) {
+    G = 32;
+    while (G > 1 && (long)G * B > 65536) G >>= 1;
+  }
+  if (h->diag) G = 64;  // phase stamps exist in the wavefront-per-solve family only
+  if (G == 64) HIP_TRY(cilqr::launch_solve_wave(a, (hipStream_t)stream));
+  else HIP_TRY(cilqr::launch_solve_groups(a, G, h->d_ws, (hipStream_t)stream));
   return CILQR_OK;
 }
 

@@ -1,0 +1,482 @@
+// cilqr_device.hpp — device-side arithmetic of the CILQR solve shared by the two kernel families:
+//   cilqr_solve.hip         one wavefront per solve, LDS-resident (small batches: one solve per SIMD)
+//   cilqr_solve_groups.hip  G lanes per solve, 64/G solves per wavefront, workspace in global memory (large batches)
+// Everything here is per (solve, step) and independent of where the data lives.  Reference citations:
+// I/ = CILQR/src/ilqr/include/ilqr/ of Leo-Liao-Chao/Uncertainty-Aware-CILQR-for-Trajectory-Optimization.
+#pragma once
+
+#include <float.h>
+
+#include "cilqr_internal.h"
+
+namespace cilqr {
+namespace dev {
+
+constexpr int WAVE = 64;
+constexpr int XR = 6;    // doubles per state record {x, y, v, theta, cos theta, sin theta}
+constexpr int REC = 16;  // doubles per linearisation record
+constexpr int KR = 10;   // doubles per gain record {k(2), K(2x4)}
+constexpr int TABF = 6;  // fields per obstacle-table entry
+
+// ---- single-instruction helpers ------------------------------------------------------------------------------------
+// One wavefront per SIMD issues one instruction every ~5 shader ticks whatever its kind (tools/ubench_issue.hip), so the
+// serial phases are priced in instructions.  These keep hipcc from adding canonicalising v_max around fmin/fmax and from
+// re-materialising 64-bit literals with s_mov pairs inside the loops.
+__device__ __forceinline__ double vmin(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double vmax(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// Pins a loop-invariant value in a vector register: after this the compiler cannot fold it back into a literal.
+#define CILQR_PIN(x) asm volatile("" : "+v"(x))
+
+// 1/x by v_rcp_f64 and two Newton steps (≤ ~1 ulp; x is a well-scaled positive determinant here).
+__device__ __forceinline__ double rcp_newton(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
+// ---- dynamics --------------------------------------------------------------------------------------------------------
+struct State {
+  double x, y, v, th, c, s;
+};
+
+// sin and cos of one fp64 argument, ≤ ~1 ulp each: three-part Cody–Waite reduction by pi/2 (exact first step under fma for
+// |x| < 2^20·pi/2) followed by the classic degree-13 / degree-14 minimax kernels on [-pi/4, pi/4].  Larger arguments (never
+// met by a heading angle) take the library path.
+__device__ __forceinline__ void sincos_fast(double x, double* sn, double* cs) {
+  if (__builtin_expect(!(fabs(x) < 1.0e6), 0)) {
+    sincos(x, sn, cs);
+    return;
+  }
+  const double n = rint(x * 6.36619772367581382433e-01);  // 2/pi
+  double r = fma(-n, 1.57079632679489655800e+00, x);      // pi/2 head: exact
+  r = fma(-n, 6.12323399573676603587e-17, r);             // pi/2 - head
+  r = fma(-n, -1.49738490485916983278e-33, r);            // next part
+  const double z = r * r;
+  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                               2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                               8.33333333332248946124e-03), -1.66666666666666324348e-01);
+  const double sr = fma(z * r, ps, r);
+  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                               -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                               -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+  const double hz = 0.5 * z;
+  const double w = 1.0 - hz;
+  const double cr = w + (((1.0 - w) - hz) + z * (z * pc));
+  const int q = (int)n;
+  const double s0 = (q & 1) ? cr : sr;
+  const double c0 = (q & 1) ? sr : cr;
+  *sn = (q & 2) ? -s0 : s0;
+  *cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// Model::forward_simulate, I/Model.cpp:17-30 (the clamps act on a copy of the control, :19-20).  The yaw-rate bounds
+// v·tan(steer)/wheelbase are taken as v·(tan(steer)/wheelbase) with the quotient formed once on the host.
+__device__ __forceinline__ State dyn_step(const KParams& kp, const State& st, double u0, double u1) {
+  const double a = fmax(fmin(u0, kp.acc_max), kp.acc_min);
+  const double w = fmax(fmin(u1, st.v * kp.yaw_hi), st.v * kp.yaw_lo);
+  const double adv = st.v * kp.dt + a * kp.half_dt2;
+  State n;
+  n.x = st.x + st.c * adv;
+  n.y = st.y + st.s * adv;
+  n.v = fmin(fmax(st.v + a * kp.dt, 0.0), kp.speed_max);
+  n.th = st.th + w * kp.dt;
+  sincos_fast(n.th, &n.s, &n.c);
+  return n;
+}
+
+struct FwdConst {  // loop invariants of the forward pass, pinned in vector registers
+  double dt, half_dt2, acc_max, acc_min, yaw_hi, yaw_lo, speed_max, zero;
+  double two_over_pi, p1, p2, p3, s1, s2, s3, s4, s5, s6, c1, c2, c3, c4, c5, c6;
+};
+__device__ __forceinline__ void make_fwd_const(FwdConst& k, const KParams& kp) {
+  k.dt = kp.dt; k.half_dt2 = kp.half_dt2; k.acc_max = kp.acc_max; k.acc_min = kp.acc_min;
+  k.yaw_hi = kp.yaw_hi; k.yaw_lo = kp.yaw_lo; k.speed_max = kp.speed_max; k.zero = 0.0;
+  k.two_over_pi = 6.36619772367581382433e-01;
+  k.p1 = 1.57079632679489655800e+00; k.p2 = 6.12323399573676603587e-17; k.p3 = -1.49738490485916983278e-33;
+  k.s1 = -1.66666666666666324348e-01; k.s2 = 8.33333333332248946124e-03; k.s3 = -1.98412698298579493134e-04;
+  k.s4 = 2.75573137070700676789e-06; k.s5 = -2.50507602534068634195e-08; k.s6 = 1.58969099521155010221e-10;
+  k.c1 = 4.16666666666666019037e-02; k.c2 = -1.38888888888741095749e-03; k.c3 = 2.48015872894767294178e-05;
+  k.c4 = -2.75573143513906633035e-07; k.c5 = 2.08757232129817482790e-09; k.c6 = -1.13596475577881948265e-11;
+  CILQR_PIN(k.dt); CILQR_PIN(k.half_dt2); CILQR_PIN(k.acc_max); CILQR_PIN(k.acc_min); CILQR_PIN(k.yaw_hi);
+  CILQR_PIN(k.yaw_lo); CILQR_PIN(k.speed_max); CILQR_PIN(k.zero); CILQR_PIN(k.two_over_pi);
+  CILQR_PIN(k.p1); CILQR_PIN(k.p2); CILQR_PIN(k.p3);
+  CILQR_PIN(k.s1); CILQR_PIN(k.s2); CILQR_PIN(k.s3); CILQR_PIN(k.s4); CILQR_PIN(k.s5); CILQR_PIN(k.s6);
+  CILQR_PIN(k.c1); CILQR_PIN(k.c2); CILQR_PIN(k.c3); CILQR_PIN(k.c4); CILQR_PIN(k.c5); CILQR_PIN(k.c6);
+}
+
+// sincos_fast without its range guard and with every constant in a register (same arithmetic, same results for
+// |x| < 1e6; callers track max|x| and hand the solve to the GENERAL kernel if that bound was ever exceeded).
+__device__ __forceinline__ void sincos_loop(const FwdConst& k, double x, double& sn, double& cs) {
+  const double n = rint(x * k.two_over_pi);
+  double r = fma(-n, k.p1, x);
+  r = fma(-n, k.p2, r);
+  r = fma(-n, k.p3, r);
+  const double z = r * r;
+  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, k.s6, k.s5), k.s4), k.s3), k.s2), k.s1);
+  const double sr = fma(z * r, ps, r);
+  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, k.c6, k.c5), k.c4), k.c3), k.c2), k.c1);
+  const double hz = 0.5 * z;
+  const double w = 1.0 - hz;
+  const double cr = w + (((1.0 - w) - hz) + z * (z * pc));
+  const int q = (int)n;
+  const bool odd = (q & 1) != 0;
+  const double s0 = odd ? cr : sr;
+  const double c0 = odd ? sr : cr;
+  const int sgs = (q & 2) << 30, sgc = ((q + 1) & 2) << 30;  // sign flips as integer xors on the high words
+  sn = __hiloint2double(__double2hiint(s0) ^ sgs, __double2loint(s0));
+  cs = __hiloint2double(__double2hiint(c0) ^ sgc, __double2loint(c0));
+}
+
+// Model::forward_simulate on the in-loop constants.
+__device__ __forceinline__ void dyn_step_loop(const FwdConst& k, State& s, double u0, double u1, double& max_th) {
+  const double a = vmax(vmin(u0, k.acc_max), k.acc_min);
+  const double w = vmax(vmin(u1, s.v * k.yaw_hi), s.v * k.yaw_lo);
+  const double adv = fma(a, k.half_dt2, s.v * k.dt);
+  s.x = fma(s.c, adv, s.x);
+  s.y = fma(s.s, adv, s.y);
+  s.v = vmin(vmax(fma(a, k.dt, s.v), k.zero), k.speed_max);
+  s.th = fma(w, k.dt, s.th);
+  max_th = vmax(max_th, fabs(s.th));
+  sincos_loop(k, s.th, s.s, s.c);
+}
+
+// One step of iLQR::forward_pass (I/iLQR.cpp:77-85): old state (ox..oth), old control (ou0, ou1), gains g[10].
+struct FwdIn {
+  double x, y, v, th, u0, u1, g[KR];
+};
+__device__ __forceinline__ void forward_step(const FwdConst& k, const FwdIn& c, State& s, double& max_th, double& u0, double& u1) {
+  const double d0 = s.x - c.x, d1 = s.y - c.y, d2 = s.v - c.v, d3 = s.th - c.th;
+  u0 = fma(c.g[5], d3, fma(c.g[4], d2, fma(c.g[3], d1, fma(c.g[2], d0, c.u0 + c.g[0]))));
+  u1 = fma(c.g[9], d3, fma(c.g[8], d2, fma(c.g[7], d1, fma(c.g[6], d0, c.u1 + c.g[1]))));
+  dyn_step_loop(k, s, u0, u1, max_th);
+}
+
+// ---- path samples and the closest-point search -----------------------------------------------------------------------
+// Sample s of the local path (I/Constraints.cpp:28-42): x_s = xf + dxs*s, y_s = sum_j c_j x_s^j with ascending powers
+// formed by repeated multiplication.  One statement of it, used wherever a sample is needed, so that every kernel sees
+// bit-identical samples.
+struct SampleGrid {
+  double xf, dxs, inv_dxs;  // inv_dxs = 1/dxs (signed)
+  bool windowed;            // false: dxs is 0 or not finite → full scan
+};
+__device__ __forceinline__ void make_sample_grid(SampleGrid& g, double xf, double xl, int S) {
+  g.xf = xf;
+  g.dxs = (xl - xf) / (double)S;
+  g.inv_dxs = 1.0 / g.dxs;
+  g.windowed = fabs(g.inv_dxs) < 1.0e300 && fabs(g.dxs) < 1.0e300 && g.dxs != 0.0;
+}
+__device__ __forceinline__ void sample_xy(const SampleGrid& g, const double* pc, int s, double& x, double& y) {
+  x = fma(g.dxs, (double)s, g.xf);
+  double acc = pc[0], pw = x;
+#pragma unroll
+  for (int j = 1; j < CILQR_POLY_COEFFS; ++j) {
+    acc = fma(pc[j], pw, acc);
+    pw *= x;
+  }
+  y = acc;
+}
+
+// Closest path sample to (px, py): index of the strict-< first minimum of the squared distance over ALL S samples
+// (I/Constraints.cpp:43-56), found without visiting all of them.  A sample can only reach the distance d_c of the sample
+// nearest in x if its own x-offset satisfies (x_s - px)² ≤ d_c, because fl(dx² + dy²) ≥ fl(dx²); the x_s are equispaced,
+// so that is an index window around (px - xf)/dxs.  The window is widened by two samples and a 1e-4 relative margin (≫ any
+// rounding in its own computation), clamped to [0, S-1] and scanned in ascending order with strict <, which yields exactly
+// the reference's argmin, ties included.  `at(s, x, y)` supplies sample s.
+template <typename SampleAt>
+__device__ __forceinline__ int closest_sample(int S, const SampleGrid& g, double px, double py, SampleAt at) {
+  auto dist = [&](int s) {
+    double sx, sy;
+    at(s, sx, sy);
+    return (sx - px) * (sx - px) + (sy - py) * (sy - py);
+  };
+  int lo = 0, hi = S - 1;
+  if (g.windowed) {
+    const double fc = (px - g.xf) * g.inv_dxs;
+    const double fcc = fmin(fmax(fc, 0.0), (double)(S - 1));  // NaN → 0
+    const double dc = dist((int)(fcc + 0.5));
+    const double hw = (double)(__builtin_sqrtf((float)dc) * 1.0001f) * fabs(g.inv_dxs) * 1.0001 + 2.0;
+    if (hw < 1.0e9) {  // false for NaN / overflow: keep the full range
+      lo = (int)fmin(fmax(fc - hw, 0.0), (double)(S - 1));
+      hi = (int)fmax(fmin(fc + hw + 1.0, (double)(S - 1)), 0.0);
+    }
+  }
+  double md = dist(lo);
+  int best = lo;
+  for (int s = lo + 1; s <= hi; s += 4) {
+    // four candidates per trip (indices past hi repeat hi: harmless under strict <), loads issued together
+    const int s1 = min(s + 1, hi), s2 = min(s + 2, hi), s3 = min(s + 3, hi);
+    const double d0 = dist(s), d1 = dist(s1), d2 = dist(s2), d3 = dist(s3);
+    if (d0 < md) { md = d0; best = s; }
+    if (d1 < md) { md = d1; best = s1; }
+    if (d2 < md) { md = d2; best = s2; }
+    if (d3 < md) { md = d3; best = s3; }
+  }
+  return best;
+}
+
+// ---- cost linearisation of one step ----------------------------------------------------------------------------------
+// Stage cost of Constraints::get_J (I/Constraints.cpp:534-561) for one step.
+__device__ __forceinline__ double stage_cost(const KParams& kp, double dx, double dy, double dv, double u0, double u1) {
+  const double xc = (dx * kp.w_pos) * dx + (dy * kp.w_pos) * dy + (dv * kp.w_vel) * dv;
+  const double uc = (u0 * kp.w_acc) * u0 + (u1 * kp.w_yawrate) * u1;
+  return xc + uc;
+}
+
+struct ObsEntry {  // one obstacle at one step, as the barrier needs it
+  double ox, oy, co, so, ia2, ib2;
+};
+// I/Obstacle.cpp:41-62: pose = (x, y, v, theta), dim = (length, width) of the obstacle at this step.
+__device__ __forceinline__ ObsEntry make_obs_entry(const KParams& kp, const double* pose, const double* dim) {
+  ObsEntry e;
+  sincos(pose[3], &e.so, &e.co);
+  const double ea = dim[0] / 2.0 + fabs(pose[2] * e.co) * kp.t_safe + kp.s_safe_a + kp.ego_rad;
+  const double eb = dim[1] / 2.0 + fabs(pose[2] * e.so) * kp.t_safe + kp.s_safe_b + kp.ego_rad + 1;
+  e.ox = pose[0];
+  e.oy = pose[1];
+  e.ia2 = 1.0 / ea / ea;
+  e.ib2 = 1.0 / eb / eb;
+  return e;
+}
+
+// One per-step linearisation record.
+struct Rec {
+  double lx0, lx1, lx2, l00, l01, l11, lu0, lu1, luu0, luu1, al, be, ga, de, p, q;
+};
+
+// Constraints::get_state_cost / get_control_cost for one step (I/Constraints.cpp:145-227, 86-137; obstacles
+// I/Obstacle.cpp:39-112) plus the six non-trivial Jacobian entries at (v_{t+1}, theta_{t+1}, a_t) (I/iLQR.cpp:102-106,
+// I/Model.cpp:100-155).  (px,py,v,ct,st): state t with cos/sin of its heading; (vn,cn,sn): speed and cos/sin heading of
+// state t+1; (cx,cy): closest path sample.  `obs(m, e, w)` supplies obstacle m at this step and its weight.
+// Returns the stage cost of get_J.
+template <typename ObsAt>
+__device__ __forceinline__ double lin_step(const KParams& kp, double px, double py, double v, double ct, double st, double u0,
+                                           double u1, double vn, double cn, double sn, double cx, double cy, int M, ObsAt obs,
+                                           Rec& r) {
+  const double dt = kp.dt;
+  // --- tracking cost (I/Constraints.cpp:163-174)
+  const double dx = px - cx, dy = py - cy, dv = v - kp.desired_speed;
+  double lx0 = (2 * kp.w_pos) * dx;
+  double lx1 = (2 * kp.w_pos) * dy;
+  const double lx2 = (2 * kp.w_vel) * dv;
+  double h00 = kp.w_pos * 2, h01 = 0.0, h11 = kp.w_pos * 2;
+  const double J = stage_cost(kp, dx, dy, dv, u0, u1);
+
+  // --- obstacles (I/Constraints.cpp:177-187, I/Obstacle.cpp:39-112)
+  const double fxp = px + ct * kp.ego_front, fyp = py + st * kp.ego_front;
+  const double rxp = px - ct * kp.ego_rear, ryp = py - st * kp.ego_rear;
+  ObsEntry e_next;
+  double w_next = 0.0;
+  if (M > 0) obs(0, e_next, w_next);
+  for (int m = 0; m < M; ++m) {
+    const ObsEntry e = e_next;
+    const double w = w_next;
+    if (m + 1 < M) obs(m + 1, e_next, w_next);  // the next entry's loads fly while this one computes
+    double gx = 0.0, gy = 0.0, gxx = 0.0, gxy = 0.0, gyy = 0.0;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      const double ex = (side == 0 ? fxp : rxp) - e.ox, ey = (side == 0 ? fyp : ryp) - e.oy;
+      const double q1 = side == 0 ? kp.q1_front : kp.q1_rear, q2 = side == 0 ? kp.q2_front : kp.q2_rear;
+      const double d0 = e.co * ex + e.so * ey;
+      const double d1 = e.co * ey - e.so * ex;
+      const double g0 = d0 * e.ia2, g1 = d1 * e.ib2;
+      const double c = 1 - (g0 * d0 + g1 * d1);
+      const double cd0 = -2 * (e.co * g0 - e.so * g1);
+      const double cd1 = -2 * (e.so * g0 + e.co * g1);
+      const double ee = exp(q2 * c);
+      const double sv = q2 * q1 * ee;
+      const double sm = q2 * q2 * q1 * ee;
+      gx += sv * cd0;
+      gy += sv * cd1;
+      gxx += (sm * cd0) * cd0;
+      gxy += (sm * cd0) * cd1;
+      gyy += (sm * cd1) * cd1;
+    }
+    lx0 += gx * w;
+    lx1 += gy * w;
+    h00 += gxx * w;
+    h01 += gxy * w;
+    h11 += gyy * w;
+  }
+
+  // --- control cost (I/Constraints.cpp:110-131)
+  const double e1 = exp(kp.q2_acc * (u0 - kp.acc_max));
+  const double e2 = exp(kp.q2_acc * (kp.acc_min - u0));
+  const double e3 = exp(kp.q2_yawrate * (u1 - v * kp.yaw_hi));
+  const double e4 = exp(kp.q2_yawrate * (v * kp.yaw_lo - u1));
+  const double sa = kp.q2_acc * kp.q1_acc, sy = kp.q2_yawrate * kp.q1_yawrate;
+  const double ma = kp.q2_acc * kp.q2_acc * kp.q1_acc, my = kp.q2_yawrate * kp.q2_yawrate * kp.q1_yawrate;
+  r.lx0 = lx0; r.lx1 = lx1; r.lx2 = lx2;
+  r.l00 = h00; r.l01 = h01; r.l11 = h11;
+  r.lu0 = (sa * e1 - sa * e2) + (2 * kp.w_acc) * u0;
+  r.lu1 = (sy * e3 - sy * e4) + (2 * kp.w_yawrate) * u1;
+  r.luu0 = ma * e1 + ma * e2 + 2 * kp.w_acc;
+  r.luu1 = my * e3 + my * e4 + 2 * kp.w_yawrate;
+
+  // --- A/B entries
+  const double adv = vn * dt + u0 * kp.half_dt2;
+  r.al = dt * cn;            // A(2,0)
+  r.be = dt * sn;            // A(2,1)
+  r.ga = (-1) * sn * adv;    // A(3,0)
+  r.de = cn * adv;           // A(3,1)
+  r.p = kp.half_dt2 * cn;    // B(0,0)
+  r.q = kp.half_dt2 * sn;    // B(0,1)
+  return J;
+}
+
+// ---- regularised Q_uu inverse ----------------------------------------------------------------------------------------
+// V diag(1/(max(eig,0)+lamb)) V' of the symmetric 2×2 [[a,b],[b,d]] (I/iLQR.cpp:155-175).
+// PSD case (always, when l_xx and l_uu are PSD: barrier Hessians are rank-one PSD): both eigenvalues pass the clamp and
+// the result is inv(Q_uu + lamb I), formed from the adjugate with one reciprocal.  bb = b².
+__device__ __forceinline__ void quu_inverse_psd(double a, double b, double d, double lamb, double bb, double& i00, double& i01,
+                                                double& i11) {
+  const double ar = a + lamb, dr = d + lamb;
+  const double rdet = rcp_newton(fma(ar, dr, -bb));
+  i00 = dr * rdet;
+  i11 = ar * rdet;
+  i01 = -b * rdet;
+}
+// General case.  With m = (a+d)/2, h = (a-d)/2, r = sqrt(h²+b²) the eigenvalues are m ± r and
+// inverse = (d1+d2)/2·I + (d1-d2)/2·[[h,b],[b,-h]]/r, d_i = 1/(max(eig_i,0)+lamb).  False for a non-finite matrix.
+__device__ __forceinline__ bool quu_inverse_general(double a, double b, double d, double lamb, double& i00, double& i01,
+                                                    double& i11) {
+  const double bb = b * b;
+  const double det0 = fma(a, d, -bb);
+  if (!(det0 == det0) || !(a + d == a + d)) return false;
+  if (det0 >= 0.0 && a + d >= 0.0) {
+    quu_inverse_psd(a, b, d, lamb, bb, i00, i01, i11);
+    return true;
+  }
+  const double mm = 0.5 * (a + d), h = 0.5 * (a - d);
+  const double rad = sqrt(fma(h, h, bb));
+  const double d1 = 1.0 / (fmax(mm + rad, 0.0) + lamb), d2 = 1.0 / (fmax(mm - rad, 0.0) + lamb);
+  const double hs = 0.5 * (d1 + d2), hd = 0.5 * (d1 - d2);
+  double c2 = 1.0, s2 = 0.0;
+  if (rad > 0.0) { c2 = h / rad; s2 = b / rad; }
+  i00 = fma(hd, c2, hs);
+  i11 = fma(-hd, c2, hs);
+  i01 = hd * s2;
+  return true;
+}
+
+// ---- one step of the backward recursion ----------------------------------------------------------------------------------
+// Value function carried by the recursion: V_x and the upper triangle of the symmetric V_xx.
+struct Value {
+  double x0, x1, x2, x3;
+  double v00, v01, v02, v03, v11, v12, v13, v22, v23, v33;
+};
+// :108-113: terminal value = stage N-1
+__device__ __forceinline__ void value_terminal(Value& V, const Rec& c, double two_wvel) {
+  V.x0 = c.lx0; V.x1 = c.lx1; V.x2 = c.lx2; V.x3 = 0.0;
+  V.v00 = c.l00; V.v01 = c.l01; V.v02 = 0.0; V.v03 = 0.0; V.v11 = c.l11; V.v12 = 0.0; V.v13 = 0.0;
+  V.v22 = two_wvel; V.v23 = 0.0; V.v33 = 0.0;
+}
+struct Gains {
+  double g[KR];  // k0, k1, K00..K03, K10..K13
+};
+
+// One step of iLQR::backward_pass (I/iLQR.cpp:133-191).
+//
+// With fx = [[1,0,0,0],[0,1,0,0],[al,be,1,0],[ga,de,0,1]] and fu = [[p,q,dt,0],[0,0,0,dt]] (the reference's
+// stored-transposed Jacobians, I/Model.cpp:100-155) the products of :149-153 reduce to one or two fused multiply-adds per
+// entry.  V_xx, Q_xx and Q_uu are carried as symmetric matrices (the reference computes both triangles, which agree to
+// rounding).
+// FAST: branch-free positive-semi-definite form; `ok` reports whether this step's Q_uu passed the PSD test (false also
+// for NaN) — callers hand solves with a failed step to the GENERAL kernel.  !FAST: branching form; `ok` false only for a
+// non-finite Q_uu (the reference's EigenSolver cannot give a real decomposition there), V and gains then untouched.
+template <bool FAST>
+__device__ __forceinline__ void riccati_step(const Rec& c, Value& V, double dt, double two_wvel, double lamb, Gains& out, bool& ok) {
+  const double al = c.al, be = c.be, ga = c.ga, de = c.de, p = c.p, q = c.q;
+  const double x0 = V.x0, x1 = V.x1, x2 = V.x2, x3 = V.x3;
+  const double v00 = V.v00, v01 = V.v01, v02 = V.v02, v03 = V.v03, v11 = V.v11, v12 = V.v12, v13 = V.v13;
+  const double v22 = V.v22, v23 = V.v23, v33 = V.v33;
+
+  // Q_x = l_x + fx V_x ; Q_u = l_u + fu V_x (:149-150)
+  const double qx0 = c.lx0 + x0;
+  const double qx1 = c.lx1 + x1;
+  const double qx2 = fma(al, x0, fma(be, x1, x2 + c.lx2));
+  const double qx3 = fma(ga, x0, fma(de, x1, x3));
+  const double qu0 = fma(p, x0, fma(q, x1, fma(dt, x2, c.lu0)));
+  const double qu1 = fma(dt, x3, c.lu1);
+
+  // T = fx V (rows 2, 3) ; Q_xx = l_xx + T fx' (:151)
+  const double t20 = fma(al, v00, fma(be, v01, v02));
+  const double t21 = fma(al, v01, fma(be, v11, v12));
+  const double t22 = fma(al, v02, fma(be, v12, v22));
+  const double t23 = fma(al, v03, fma(be, v13, v23));
+  const double t30 = fma(ga, v00, fma(de, v01, v03));
+  const double t31 = fma(ga, v01, fma(de, v11, v13));
+  const double t33 = fma(ga, v03, fma(de, v13, v33));
+  const double q00 = v00 + c.l00, q01 = v01 + c.l01, q11 = v11 + c.l11;
+  const double q22 = fma(al, t20, fma(be, t21, t22 + two_wvel));
+  const double q23 = fma(ga, t20, fma(de, t21, t23));
+  const double q33 = fma(ga, t30, fma(de, t31, t33));
+
+  // E = fu V ; Q_ux = E fx' ; Q_uu = l_uu + E fu' (:152-153)
+  const double e00 = fma(p, v00, fma(q, v01, dt * v02));
+  const double e01 = fma(p, v01, fma(q, v11, dt * v12));
+  const double e02 = fma(p, v02, fma(q, v12, dt * v22));
+  const double e03 = fma(p, v03, fma(q, v13, dt * v23));
+  const double e10 = dt * v03, e11 = dt * v13, e12 = dt * v23, e13 = dt * v33;
+  const double ux02 = fma(al, e00, fma(be, e01, e02));
+  const double ux03 = fma(ga, e00, fma(de, e01, e03));
+  const double ux12 = fma(al, e10, fma(be, e11, e12));
+  const double ux13 = fma(ga, e10, fma(de, e11, e13));
+  const double a = fma(p, e00, fma(q, e01, fma(dt, e02, c.luu0)));
+  const double b = dt * e03;
+  const double d = fma(dt, e13, c.luu1);
+
+  double i00, i01, i11;
+  if (FAST) {
+    const double bb = b * b;
+    const double det0 = fma(a, d, -bb);
+    ok = (det0 >= 0.0) & (a + d >= 0.0);
+    quu_inverse_psd(a, b, d, lamb, bb, i00, i01, i11);
+  } else {
+    ok = quu_inverse_general(a, b, d, lamb, i00, i01, i11);
+    if (!ok) return;
+  }
+
+  // k = -Qinv Q_u ; K = -Qinv Q_ux (:177-178)
+  const double k0 = fma(-i00, qu0, -(i01 * qu1));
+  const double k1 = fma(-i01, qu0, -(i11 * qu1));
+  const double K00 = fma(-i00, e00, -(i01 * e10)), K01 = fma(-i00, e01, -(i01 * e11));
+  const double K02 = fma(-i00, ux02, -(i01 * ux12)), K03 = fma(-i00, ux03, -(i01 * ux13));
+  const double K10 = fma(-i01, e00, -(i11 * e10)), K11 = fma(-i01, e01, -(i11 * e11));
+  const double K12 = fma(-i01, ux02, -(i11 * ux12)), K13 = fma(-i01, ux03, -(i11 * ux13));
+
+  // G = K' Q_uu (unregularised) ; V_x = Q_x - G k ; V_xx = Q_xx - G K (:180-181)
+  const double g00 = fma(K00, a, K10 * b), g01 = fma(K00, b, K10 * d);
+  const double g10 = fma(K01, a, K11 * b), g11 = fma(K01, b, K11 * d);
+  const double g20 = fma(K02, a, K12 * b), g21 = fma(K02, b, K12 * d);
+  const double g30 = fma(K03, a, K13 * b), g31 = fma(K03, b, K13 * d);
+  V.x0 = fma(-g01, k1, fma(-g00, k0, qx0));
+  V.x1 = fma(-g11, k1, fma(-g10, k0, qx1));
+  V.x2 = fma(-g21, k1, fma(-g20, k0, qx2));
+  V.x3 = fma(-g31, k1, fma(-g30, k0, qx3));
+  V.v00 = fma(-g01, K10, fma(-g00, K00, q00));
+  V.v01 = fma(-g01, K11, fma(-g00, K01, q01));
+  V.v02 = fma(-g01, K12, fma(-g00, K02, t20));
+  V.v03 = fma(-g01, K13, fma(-g00, K03, t30));
+  V.v11 = fma(-g11, K11, fma(-g10, K01, q11));
+  V.v12 = fma(-g11, K12, fma(-g10, K02, t21));
+  V.v13 = fma(-g11, K13, fma(-g10, K03, t31));
+  V.v22 = fma(-g21, K12, fma(-g20, K02, q22));
+  V.v23 = fma(-g21, K13, fma(-g20, K03, q23));
+  V.v33 = fma(-g31, K13, fma(-g30, K03, q33));
+
+  out.g[0] = k0; out.g[1] = k1;
+  out.g[2] = K00; out.g[3] = K01; out.g[4] = K02; out.g[5] = K03;
+  out.g[6] = K10; out.g[7] = K11; out.g[8] = K12; out.g[9] = K13;
+}
+
+}  // namespace dev
+}  // namespace cilqr

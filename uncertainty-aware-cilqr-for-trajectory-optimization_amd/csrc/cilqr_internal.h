@@ -48,8 +48,12 @@ struct SolveArgs {
 };
 
 // Launchers (defined in the .hip files). All are asynchronous on `stream`.
-hipError_t launch_solve(const SolveArgs& a, hipStream_t stream);
+// One wavefront per solve, LDS-resident (cilqr_solve.hip).
+hipError_t launch_solve_wave(const SolveArgs& a, hipStream_t stream);
 size_t solve_lds_bytes(int N, int n_samples);
+// G lanes per solve (G in {1,2,4,8,16,32}), workspace `ws` of solve_groups_ws_doubles(B, N) doubles (cilqr_solve_groups.hip).
+hipError_t launch_solve_groups(const SolveArgs& a, int G, double* ws, hipStream_t stream);
+size_t solve_groups_ws_doubles(int B, int N);
 hipError_t launch_quu_inverse(int n, const double* q, const double* lamb, double* out, int general, hipStream_t stream);
 
 hipError_t launch_argmin(const double* J, int B, double* out_pair, double* scratch, hipStream_t stream);

@@ -1,0 +1,344 @@
+// cilqr_solve_groups.hip — batched constrained-iLQR solve for gfx950 (MI355X), G LANES PER SOLVE, 64/G solves per
+// wavefront, per-solve arrays in a global-memory workspace.  The kernel family for batches larger than about one solve
+// per SIMD (cilqr_solve.hip holds the one-wavefront-per-solve, LDS-resident family; launch_solve picks).
+//
+// Why a second mapping.  A wavefront issues one instruction per ≈5 ticks whatever it is.  In the one-wavefront-per-solve
+// kernel the sequential phases (backward Riccati recursion R, forward pass F; I/iLQR.cpp:133-191, 68-86) keep 1 useful
+// lane in 64, and LDS (≈20-30 KiB per solve) caps residency at 5-8 solves per CU, so a large batch runs in many rounds at
+// a few per cent lane use.  Here a wavefront carries S = 64/G solves: R and F run once for S solves (lanes of a group
+// compute redundantly, groups differ), the lane-parallel linearisation L (I/Constraints.cpp:145-227, 86-137) spreads each
+// solve's N steps over its G lanes, and the arrays live in global memory laid out [row][solve-in-wavefront] so that a
+// wavefront instruction touches S consecutive doubles per row (L2 / Infinity-Cache resident for the batch sizes this is
+// chosen for).  launch_solve picks G ≈ 65536/B (power of two) so that the grid is about one wavefront per SIMD.
+//
+// Arithmetic is shared with the LDS family (cilqr_device.hpp): same per-step functions, same samples, same fast/GENERAL
+// split with the redo hand-over.  Path samples are recomputed where needed (12 instructions) instead of stored.
+#include "cilqr_device.hpp"
+
+namespace cilqr {
+
+using namespace dev;
+
+namespace {
+
+// Per-wavefront workspace block, in rows of S doubles (one column per solve of the wavefront), FIELD-major:
+// row(field f of an array, step t) = array base + f*(steps of that array) + t.  In phase L the 64 lanes (step t = g + k·G,
+// solve grp) of one load instruction then cover G·S = 64 consecutive doubles (512 B, fully coalesced); in the serial
+// phases the lanes of a group share a row and the S groups read S consecutive doubles.
+struct WsLayout {
+  int N, M;
+  __device__ __host__ int xa() const { return 0; }
+  __device__ __host__ int xb() const { return (N + 1) * XR; }
+  __device__ __host__ int ua() const { return 2 * (N + 1) * XR; }
+  __device__ __host__ int ub() const { return ua() + 2 * N; }
+  __device__ __host__ int rec() const { return ub() + 2 * N; }
+  __device__ __host__ int kk() const { return rec() + REC * N; }
+  __device__ __host__ int rows() const { return kk() + KR * N; }
+};
+
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+
+__device__ __forceinline__ void mem_sync() {
+  // stores of one lane are read by other lanes of the same wavefront through global memory: drain and re-order
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <int G, bool GENERAL>
+__global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, double* ws_base) {
+  constexpr int S = WAVE / G;
+  const int lane = threadIdx.x, grp = lane / G, g = lane % G;
+  const int b = blockIdx.x * S + grp;
+  if (b >= a.B) return;  // whole groups leave together
+  if (GENERAL && a.redo[b] == 0) return;
+  const KParams kp = a.kp;
+  const int N = a.N, M = a.M, NS = kp.n_samples;
+  const WsLayout L{N, M};
+
+  // column `grp` of this wavefront's block: element (row r) at ws[r * S]
+  double* ws = ws_base + (size_t)blockIdx.x * L.rows() * S + grp;
+  double* tab = a.obs_tab + (size_t)blockIdx.x * ((size_t)M * N * TABF) * S + grp;  // rows ((m*6 + f)*N + t)
+#define XF(base, t, f) ws[(size_t)((base) + (f) * (N + 1) + (t)) * S] /* state arrays: 6 fields x (N+1) steps */
+#define UF(base, t, f) ws[(size_t)((base) + (f) * N + (t)) * S]       /* control arrays: 2 fields x N steps */
+#define RF(t, f) ws[(size_t)(L.rec() + (f) * N + (t)) * S]            /* linearisation: 16 fields x N steps */
+#define KF(t, f) ws[(size_t)(L.kk() + (f) * N + (t)) * S]             /* gains: 10 fields x N steps */
+
+  // ---- prologue -------------------------------------------------------------------------------------------
+  double pc[CILQR_POLY_COEFFS];
+#pragma unroll
+  for (int j = 0; j < CILQR_POLY_COEFFS; ++j) pc[j] = a.poly[(size_t)b * CILQR_POLY_COEFFS + j];
+  SampleGrid grid;
+  make_sample_grid(grid, a.xplan_fl[2 * b], a.xplan_fl[2 * b + 1], NS);
+  auto sample_at = [&](int s, double& x, double& y) { sample_xy(grid, pc, s, x, y); };
+
+  double* Ug = a.U + (size_t)b * 2 * N;
+  for (int t = g; t < N; t += G) {
+    UF(L.ua(), t, 0) = Ug[2 * t];
+    UF(L.ua(), t, 1) = Ug[2 * t + 1];
+  }
+  const double* wts = a.obs_weight ? a.obs_weight + (size_t)b * M : nullptr;
+  for (int m = 0; m < M; ++m)  // obstacle table, I/Obstacle.cpp:41-62
+    for (int t = g; t < N; t += G) {
+      const ObsEntry e = make_obs_entry(kp, a.obs_pose + (((size_t)b * M + m) * N + t) * 4, a.obs_dim + (((size_t)b * M + m) * N + t) * 2);
+      double* o = tab + (size_t)(m * TABF * N + t) * S;
+      const size_t fs = (size_t)N * S;  // field stride
+      o[0] = e.ox; o[fs] = e.oy; o[2 * fs] = e.co; o[3 * fs] = e.so; o[4 * fs] = e.ia2; o[5 * fs] = e.ib2;
+    }
+  mem_sync();
+
+  auto store_state = [&](int base, int t, const State& s) {
+    if (g == 0) {
+      XF(base, t, 0) = s.x; XF(base, t, 1) = s.y; XF(base, t, 2) = s.v;
+      XF(base, t, 3) = s.th; XF(base, t, 4) = s.c; XF(base, t, 5) = s.s;
+    }
+  };
+
+  bool handover = false;
+  {  // nominal rollout, I/iLQR.cpp:51-62
+    const double* x0 = a.x0 + (size_t)b * 4;
+    State s;
+    s.x = x0[0]; s.y = x0[1]; s.v = x0[2]; s.th = x0[3];
+    if (GENERAL) {
+      sincos_fast(s.th, &s.s, &s.c);
+      store_state(L.xa(), 0, s);
+      for (int i = 0; i < N; ++i) {
+        s = dyn_step(kp, s, UF(L.ua(), i, 0), UF(L.ua(), i, 1));
+        store_state(L.xa(), i + 1, s);
+      }
+    } else {
+      FwdConst k;
+      make_fwd_const(k, kp);
+      double max_th = fabs(s.th);
+      sincos_loop(k, s.th, s.s, s.c);
+      store_state(L.xa(), 0, s);
+      for (int i = 0; i < N; ++i) {
+        dyn_step_loop(k, s, UF(L.ua(), i, 0), UF(L.ua(), i, 1), max_th);
+        store_state(L.xa(), i + 1, s);
+      }
+      handover = !(max_th < 1.0e6);
+    }
+  }
+  mem_sync();
+
+  // ---- iteration loop, I/iLQR.cpp:204-239 (per group; groups of one wavefront diverge freely) -----------------------
+  int xc = L.xa(), xn = L.xb(), uc = L.ua(), un = L.ub();
+  double J_old = DBL_MAX, lamb = 1.0, J_new = 0.0;
+  int iters = 0, status = CILQR_EXIT_MAX_ITER;
+  bool j_valid = false;
+  const bool faithful = (a.flags & CILQR_FLAG_FAITHFUL_ITERS) != 0;
+  const int max_it = kp.max_iterations;
+  const double dt = kp.dt, two_wvel = kp.w_vel * 2;
+
+  for (int it = 0; it < max_it && !handover; ++it) {
+    ++iters;
+    // ---- phase L: this group's N steps over its G lanes
+    double Jpart = 0.0;
+    for (int t = g; t < N; t += G) {
+      const double px = XF(xc, t, 0), py = XF(xc, t, 1);
+      const int cs = closest_sample(NS, grid, px, py, sample_at);
+      double cx, cy;
+      sample_xy(grid, pc, cs, cx, cy);
+      const double* tt = tab + (size_t)t * S;
+      const size_t fs = (size_t)N * S;
+      auto obs = [&](int m, ObsEntry& e, double& w) {
+        const double* p = tt + (size_t)m * TABF * fs;
+        e.ox = p[0]; e.oy = p[fs]; e.co = p[2 * fs]; e.so = p[3 * fs]; e.ia2 = p[4 * fs]; e.ib2 = p[5 * fs];
+        w = wts ? wts[m] : kp.w_obstacle;
+      };
+      Rec c;
+      Jpart += lin_step(kp, px, py, XF(xc, t, 2), XF(xc, t, 4), XF(xc, t, 5), UF(uc, t, 0), UF(uc, t, 1), XF(xc, t + 1, 2),
+                        XF(xc, t + 1, 4), XF(xc, t + 1, 5), cx, cy, M, obs, c);
+      RF(t, 0) = c.lx0; RF(t, 1) = c.lx1; RF(t, 2) = c.lx2; RF(t, 3) = c.l00; RF(t, 4) = c.l01; RF(t, 5) = c.l11;
+      RF(t, 6) = c.lu0; RF(t, 7) = c.lu1; RF(t, 8) = c.luu0; RF(t, 9) = c.luu1;
+      RF(t, 10) = c.al; RF(t, 11) = c.be; RF(t, 12) = c.ga; RF(t, 13) = c.de; RF(t, 14) = c.p; RF(t, 15) = c.q;
+    }
+    J_new = group_sum<G>(Jpart);
+    j_valid = true;
+    mem_sync();
+
+    const bool accept = J_new < J_old;
+    if (!accept && !faithful) {
+      if (J_new != J_new) { status = CILQR_EXIT_NUMERIC; break; }
+      for (;;) {
+        lamb = lamb * kp.lamb_factor;
+        if (lamb > kp.lamb_max) { status = CILQR_EXIT_LAMBDA_MAX; break; }
+        if (++it >= max_it) { status = CILQR_EXIT_MAX_ITER; break; }
+        ++iters;
+      }
+      break;
+    }
+
+    // ---- phase R: backward recursion (all lanes of the group compute the same values)
+    bool r_ok = true;
+    {
+      auto load_rec = [&](Rec& o, int j) {
+        o.lx0 = RF(j, 0); o.lx1 = RF(j, 1); o.lx2 = RF(j, 2); o.l00 = RF(j, 3); o.l01 = RF(j, 4); o.l11 = RF(j, 5);
+        o.lu0 = RF(j, 6); o.lu1 = RF(j, 7); o.luu0 = RF(j, 8); o.luu1 = RF(j, 9);
+        o.al = RF(j, 10); o.be = RF(j, 11); o.ga = RF(j, 12); o.de = RF(j, 13); o.p = RF(j, 14); o.q = RF(j, 15);
+      };
+      Rec ra, rb;
+      load_rec(ra, N - 1);
+      Value V;
+      value_terminal(V, ra, two_wvel);
+      Gains gn;
+      bool ok;
+      auto step = [&](const Rec& c, int j) {
+        riccati_step<!GENERAL>(c, V, dt, two_wvel, lamb, gn, ok);
+        r_ok = r_ok && ok;
+        if (g == 0 && (!GENERAL || ok)) {
+#pragma unroll
+          for (int i = 0; i < KR; ++i) KF(j, i) = gn.g[i];
+        }
+      };
+      int j = N - 1;
+      for (; j >= 1 && (!GENERAL || r_ok); j -= 2) {
+        load_rec(rb, j - 1);
+        step(ra, j);
+        load_rec(ra, j >= 2 ? j - 2 : 0);
+        if (!GENERAL || r_ok) step(rb, j - 1);
+      }
+      if (j == 0 && (!GENERAL || r_ok)) step(ra, 0);
+    }
+    if (!r_ok) {
+      if (GENERAL) { status = CILQR_EXIT_NUMERIC; break; }
+      handover = true;
+      break;
+    }
+    mem_sync();
+
+    // ---- phase F: forward pass
+    {
+      State s;
+      s.x = XF(xc, 0, 0); s.y = XF(xc, 0, 1); s.v = XF(xc, 0, 2); s.th = XF(xc, 0, 3); s.c = XF(xc, 0, 4); s.s = XF(xc, 0, 5);
+      store_state(xn, 0, s);
+      auto load_fwd = [&](FwdIn& o, int i) {
+        o.x = XF(xc, i, 0); o.y = XF(xc, i, 1); o.v = XF(xc, i, 2); o.th = XF(xc, i, 3);
+        o.u0 = UF(uc, i, 0); o.u1 = UF(uc, i, 1);
+#pragma unroll
+        for (int k = 0; k < KR; ++k) o.g[k] = KF(i, k);
+      };
+      if (GENERAL) {
+        for (int i = 0; i < N; ++i) {
+          FwdIn c;
+          load_fwd(c, i);
+          const double d0 = s.x - c.x, d1 = s.y - c.y, d2 = s.v - c.v, d3 = s.th - c.th;
+          const double u0 = fma(c.g[5], d3, fma(c.g[4], d2, fma(c.g[3], d1, fma(c.g[2], d0, c.u0 + c.g[0]))));
+          const double u1 = fma(c.g[9], d3, fma(c.g[8], d2, fma(c.g[7], d1, fma(c.g[6], d0, c.u1 + c.g[1]))));
+          s = dyn_step(kp, s, u0, u1);
+          if (g == 0) { UF(un, i, 0) = u0; UF(un, i, 1) = u1; }
+          store_state(xn, i + 1, s);
+        }
+      } else {
+        FwdConst k;
+        make_fwd_const(k, kp);
+        double max_th = fabs(s.th);
+        FwdIn fa, fb;
+        load_fwd(fa, 0);
+        auto step = [&](const FwdIn& c, int i) {
+          double u0, u1;
+          forward_step(k, c, s, max_th, u0, u1);
+          if (g == 0) { UF(un, i, 0) = u0; UF(un, i, 1) = u1; }
+          store_state(xn, i + 1, s);
+        };
+        int i = 0;
+        for (; i + 1 < N; i += 2) {
+          load_fwd(fb, i + 1);
+          step(fa, i);
+          load_fwd(fa, i + 2 < N ? i + 2 : i + 1);
+          step(fb, i + 1);
+        }
+        if (i < N) step(fa, i);
+        if (!(max_th < 1.0e6)) { handover = true; break; }
+      }
+    }
+    mem_sync();
+
+    if (accept) {
+      int t0 = xc; xc = xn; xn = t0;
+      int t1 = uc; uc = un; un = t1;
+      j_valid = false;
+      lamb = lamb / kp.lamb_factor;
+      if (fabs(J_new - J_old) < kp.tolerance) { status = CILQR_EXIT_TOLERANCE; break; }
+    } else {
+      lamb = lamb * kp.lamb_factor;
+      if (lamb > kp.lamb_max) { status = CILQR_EXIT_LAMBDA_MAX; break; }
+    }
+    J_old = J_new;
+  }
+
+  if (!GENERAL) {
+    if (g == 0) a.redo[b] = handover ? 1 : 0;
+    if (handover) return;
+  }
+
+  // ---- epilogue: X_result / U_result (:243-244)
+  for (int t = g; t < N; t += G) {
+    Ug[2 * t] = UF(uc, t, 0);
+    Ug[2 * t + 1] = UF(uc, t, 1);
+  }
+  double* Xg = a.X_out + (size_t)b * 4 * (N + 1);
+  for (int t = g; t <= N; t += G) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Xg[4 * t + r] = XF(xc, t, r);
+  }
+  if (a.J_out) {
+    if (!j_valid) {
+      double Jpart = 0.0;
+      for (int t = g; t < N; t += G) {
+        const double px = XF(xc, t, 0), py = XF(xc, t, 1);
+        const int cs = closest_sample(NS, grid, px, py, sample_at);
+        double cx, cy;
+        sample_xy(grid, pc, cs, cx, cy);
+        Jpart += stage_cost(kp, px - cx, py - cy, XF(xc, t, 2) - kp.desired_speed, UF(uc, t, 0), UF(uc, t, 1));
+      }
+      J_new = group_sum<G>(Jpart);
+    }
+    if (g == 0) a.J_out[b] = J_new;
+  }
+  if (g == 0) {
+    if (a.iters_out) a.iters_out[b] = iters;
+    if (a.status_out) a.status_out[b] = status;
+  }
+#undef XF
+#undef UF
+#undef RF
+#undef KF
+}
+
+template <int G>
+void launch_g(const SolveArgs& a, double* ws, hipStream_t stream) {
+  constexpr int S = WAVE / G;
+  const int blocks = (a.B + S - 1) / S;
+  hipLaunchKernelGGL((cilqr_solve_groups_kernel<G, false>), dim3(blocks), dim3(WAVE), 0, stream, a, ws);
+  hipLaunchKernelGGL((cilqr_solve_groups_kernel<G, true>), dim3(blocks), dim3(WAVE), 0, stream, a, ws);
+}
+
+}  // namespace
+
+size_t solve_groups_ws_doubles(int B, int N) {
+  // padded to whole wavefronts of the narrowest grouping (G = 1 → 64 solves per wavefront)
+  const size_t Bp = ((size_t)B + WAVE - 1) / WAVE * WAVE;
+  const WsLayout L{N, 0};
+  return Bp * (size_t)L.rows();
+}
+
+hipError_t launch_solve_groups(const SolveArgs& a, int G, double* ws, hipStream_t stream) {
+  if (a.B <= 0) return hipSuccess;
+  switch (G) {
+    case 1: launch_g<1>(a, ws, stream); break;
+    case 2: launch_g<2>(a, ws, stream); break;
+    case 4: launch_g<4>(a, ws, stream); break;
+    case 8: launch_g<8>(a, ws, stream); break;
+    case 16: launch_g<16>(a, ws, stream); break;
+    case 32: launch_g<32>(a, ws, stream); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace cilqr
