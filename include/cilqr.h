@@ -17,6 +17,7 @@
  *   Constraints::get_J                  I/Constraints.cpp:534-561   J_out of cilqr_solve_batch
  *   LocalPlanner::get_local_plan(_coeffs) I/LocalPlanner.cpp:25-117 cilqr_local_plan (host pre-step)
  *   LocalCostmap::odomCallback warp loop M/src/local_costmap.cpp:242-264 cilqr_warp_costmap(_device)
+ *   thrust_propagateUncertainty     M/src/arbitrary_transformation.cu:8-157  cilqr_blur_costmap(_device)
  *   (none: batch min-cost selection is new)      cilqr_argmin_device
  *
  * Conventions
@@ -211,6 +212,18 @@ int cilqr_warp_costmap_device(cilqr_handle* h, void* stream, const float* src, c
                               float* dst, const cilqr_map_geom* dst_geom,
                               double vx, double vy, double vtheta, const float* bbox,
                               int64_t* n_out_of_range_dev);
+/* --- pose-uncertainty propagation over the vehicle-frame costmap ("blur") ---------- */
+/* thrust_propagateUncertainty (M/src/arbitrary_transformation.cu:8-157, functors M/include/ARBIT.cuh:51-107) together with
+ * the copy-through of LocalCostmap::propagateUncertainty (M/src/local_costmap.cpp:483-496): for every cell with linear
+ * (column-major) index ≥ index, the pose-uncertainty covariance at the cell → 95 % confidence ellipse → Gaussian-weighted
+ * average of the `src` layer over the cells inside it; an empty ellipse copies the cell through; cells before `index` are
+ * NaN.  src/out: float32 column-major layers of geometry g.  count_out (optional): cells inside each ellipse.
+ * vtheta: vehicle heading (the reference passes its sine and cosine). */
+int cilqr_blur_costmap(cilqr_handle* h, const float* src, const cilqr_map_geom* g, int index, double vtheta, double sigma_x,
+                       double sigma_y, double sigma_theta, float* out, int32_t* count_out);
+int cilqr_blur_costmap_device(cilqr_handle* h, void* stream, const float* src, const cilqr_map_geom* g, int index, double vtheta,
+                              double sigma_x, double sigma_y, double sigma_theta, float* out, int32_t* count_out);
+
 /* setGeometry(Length(lx,ly), res, Position(px,py)) size/length rule (G/grid_map_core/src/GridMap.cpp:45-62). */
 int cilqr_map_geom_set(cilqr_map_geom* g, double len_x, double len_y, double res, double pos_x, double pos_y);
 

@@ -93,6 +93,14 @@ int  oracle_map_get_index(const cilqr_map_geom* g, double px, double py, int* i,
 long oracle_warp_costmap(const float* src, const cilqr_map_geom* sg, float* dst, const cilqr_map_geom* dg,
                          double vx, double vy, double vtheta, const float* bbox, int threads);
 
+/* Uncertainty propagation ("blur"): M/src/arbitrary_transformation.cu:8-157, M/include/ARBIT.cuh:51-107,
+ * M/src/local_costmap.cpp:474-498 over G/grid_map_core EllipseIterator.  src/out: float32 column-major layers of geometry g;
+ * cells with linear index < index are left NaN (the reference never writes them).  Returns the number of cells whose
+ * ellipse was empty (copy-through).  count_out (optional): cells inside each ellipse. */
+void oracle_blur_ellipse(double a, double b, double c, double* half_major, double* half_minor, double* angle);
+long oracle_blur(const float* src, const cilqr_map_geom* g, int index, double sin_t, double cos_t, double sigma_x,
+                 double sigma_y, double sigma_theta, float* out, int* count_out, int threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,7 @@ def lib():
         L = C.CDLL(path)
         L.oracle_get_J.restype = C.c_double
         L.oracle_warp_costmap.restype = C.c_long
+        L.oracle_blur.restype = C.c_long
         _lib = L
     return _lib
 
@@ -172,3 +173,31 @@ def warp(src, sg, dg, vx, vy, vtheta, bbox=None, threads=1):
     n = lib().oracle_warp_costmap(src.ctypes.data_as(c_float_p), C.byref(sg), dst.ctypes.data_as(c_float_p),
                                   C.byref(dg), C.c_double(vx), C.c_double(vy), C.c_double(vtheta), bb, int(threads))
     return dst, int(n)
+
+
+def blur(src, g, sin_t, cos_t, sigma_x, sigma_y, sigma_theta, index=0, threads=1):
+    """src: (rows, cols) float32.  Returns (out F-ordered float32, counts (rows*cols,) int32 in linear cell order, n_empty)."""
+    src = np.asfortranarray(src, dtype=np.float32)
+    assert src.shape == (g.rows, g.cols)
+    out = np.zeros((g.rows, g.cols), dtype=np.float32, order="F")
+    cnt = np.zeros(g.rows * g.cols, dtype=np.int32)
+    n = lib().oracle_blur(src.ctypes.data_as(c_float_p), C.byref(g), int(index), C.c_double(sin_t), C.c_double(cos_t),
+                          C.c_double(sigma_x), C.c_double(sigma_y), C.c_double(sigma_theta), out.ctypes.data_as(c_float_p),
+                          cnt.ctypes.data_as(c_int_p), int(threads))
+    return out, cnt, int(n)
+
+
+def ref_blur(src, geom_args, sin_t, cos_t, sigma_x, sigma_y, sigma_theta, index=0):
+    """The same through the reference's own grid_map_core + Eigen (oracle/_ref); None when _ref is not built."""
+    L = ref_lib("gridmap")
+    if L is None:
+        return None
+    g = map_geom(*geom_args)
+    src = np.asfortranarray(src, dtype=np.float32)
+    out = np.zeros((g.rows, g.cols), dtype=np.float32, order="F")
+    cnt = np.zeros(g.rows * g.cols, dtype=np.int32)
+    ell = np.zeros(3 * g.rows * g.cols)
+    L.ref_blur(src.ctypes.data_as(c_float_p), *[C.c_double(v) for v in geom_args], int(index), C.c_double(sin_t), C.c_double(cos_t),
+               C.c_double(sigma_x), C.c_double(sigma_y), C.c_double(sigma_theta), out.ctypes.data_as(c_float_p),
+               cnt.ctypes.data_as(c_int_p), ell.ctypes.data_as(c_double_p))
+    return out, cnt, ell.reshape(-1, 3)

@@ -90,3 +90,83 @@ long ref_warp(const float* src, double slx, double sly, double sres, double spx,
 }
 
 }  // extern "C"
+
+// ---- uncertainty propagation ("blur"), M/src/arbitrary_transformation.cu:8-157 + M/include/ARBIT.cuh:51-107 ------------
+// This driver's statement of the recipe over the reference's own grid_map_core (EllipseIterator, GridMap) and the
+// reference's vendored Eigen (EigenSolver<Matrix2f>).  The three thrust functors are a dozen arithmetic lines; they are
+// restated here because ARBIT.cuh cannot be included without CUDA/thrust/OpenCV/ROS headers.
+#include <Eigen/Eigenvalues>
+
+#include "grid_map_core/iterators/EllipseIterator.hpp"
+
+extern "C" void ref_blur(const float* src, double lx, double ly, double res, double px, double py, int index, double sin_t,
+                         double cos_t, double sigma_x, double sigma_y, double sigma_theta, float* out, int* count_out,
+                         double* ellipse_out /* 3 per cell or null */) {
+  GridMap m;
+  m.add("vehicle_map");
+  m.add("uncertainty_map");
+  m.setGeometry(Length(lx, ly), res, Position(px, py));
+  {
+    grid_map::Matrix& g = m["vehicle_map"];
+    for (long k = 0; k < (long)g.size(); k++) g.data()[k] = src[k];
+    grid_map::Matrix& u = m["uncertainty_map"];
+    for (long k = 0; k < (long)u.size(); k++) u.data()[k] = NAN;
+  }
+  grid_map::GridMapIterator it(m);
+  for (int i = 0; i < index; ++i) ++it;
+  long lin = index;
+  for (; !it.isPastEnd(); ++it, ++lin) {
+    Position position;
+    m.getPosition(*it, position);
+    const double Cx = position.x(), Cy = position.y();
+    // uncertainty_error_functor (ARBIT.cuh:59-68)
+    const double u = (-sin_t * Cx - cos_t * Cy) * (-sin_t * Cx - cos_t * Cy);
+    const double v = (cos_t * Cx - sin_t * Cy) * (cos_t * Cx - sin_t * Cy);
+    const double t = sin_t * cos_t * (Cx * Cx - Cy * Cy) + Cx * Cy * (sin_t * sin_t - cos_t * cos_t);
+    const double sigma_x_i = sqrt(sigma_x * sigma_x + sigma_theta * sigma_theta * u);
+    const double sigma_y_i = sqrt(sigma_y * sigma_y + sigma_theta * sigma_theta * v);
+    const double rho = sigma_theta * sigma_theta * t / (sigma_x_i * sigma_y_i);
+    // abc_functor (:74-79)
+    const double a = sigma_x_i * sigma_x_i, b = rho * sigma_x_i * sigma_y_i, c = sigma_y_i * sigma_y_i;
+    // host loop arbitrary_transformation.cu:60-83
+    Eigen::Matrix2f cov_i;
+    double temp0 = a, temp1 = b, temp2 = c;
+    cov_i << temp0, temp1, temp1, temp2;
+    Eigen::EigenSolver<Eigen::Matrix2f> es(cov_i);
+    Eigen::Matrix2f D = es.pseudoEigenvalueMatrix();
+    Eigen::Matrix2f V = es.pseudoEigenvectors();
+    int major_index, minor_index;
+    if (D(0, 0) > D(1, 1)) { major_index = 0; minor_index = 1; } else { major_index = 1; minor_index = 0; }
+    // ellipse_params_functor (ARBIT.cuh:85-97)
+    const double chisquare_val = 2.4477;
+    double angle = atan2(V(major_index, 1), V(major_index, 0));
+    if (angle < 0) angle += 6.28318530718;
+    const double half_major_axis = chisquare_val * sqrt(D(major_index, major_index));
+    const double half_minor_axis = chisquare_val * sqrt(D(minor_index, minor_index));
+    if (ellipse_out) { ellipse_out[3 * lin] = half_major_axis; ellipse_out[3 * lin + 1] = half_minor_axis; ellipse_out[3 * lin + 2] = angle; }
+    // OpenMP loop body arbitrary_transformation.cu:104-138
+    double numerator = 0, denominator = 0;
+    int count = 0;
+    for (grid_map::EllipseIterator iterator(m, position, Length(2 * half_major_axis, 2 * half_minor_axis), angle);
+         !iterator.isPastEnd(); ++iterator) {
+      Position position_j;
+      m.getPosition(*iterator, position_j);
+      const double x = position_j.x(), y = position_j.y(), mu1 = Cx, mu2 = Cy, sigma1 = sigma_x_i, sigma2 = sigma_y_i;
+      // nomal2 (ARBIT.cuh:103-107)
+      const double f_i = 1.0 / (sqrt(1 - rho * rho) * (2 * M_PI * sigma1 * sigma2)) *
+                         exp((-1 / (2 * (1 - rho * rho))) * ((x - mu1) * (x - mu1) / (sigma1 * sigma1) -
+                                                           2 * rho * (x - mu1) * (y - mu2) / (sigma1 * sigma2) +
+                                                           (y - mu2) * (y - mu2) / (sigma2 * sigma2)));
+      numerator += f_i * m.atPosition("vehicle_map", position_j);
+      denominator += f_i;
+      count++;
+    }
+    const double result = numerator / denominator;
+    // LocalCostmap::propagateUncertainty (M/src/local_costmap.cpp:483-496)
+    if (count == 0) m.at("uncertainty_map", *it) = m.at("vehicle_map", *it);
+    else m.at("uncertainty_map", *it) = result;
+    if (count_out) count_out[lin] = count;
+  }
+  const grid_map::Matrix& u = m["uncertainty_map"];
+  for (long k = 0; k < (long)u.size(); k++) out[k] = u.data()[k];
+}

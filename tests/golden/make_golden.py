@@ -207,6 +207,32 @@ def gen_oracle_solves():
     dump("oracle_solves.json", out)
 
 
+def gen_blur():
+    """Small maps through the reference's grid_map_core EllipseIterator + vendored Eigen float EigenSolver."""
+    rng = np.random.Generator(np.random.PCG64(14))
+    out = {"source": "M/src/arbitrary_transformation.cu:8-157 recipe over the reference's grid_map_core + Eigen 3.2.10 (oracle/_ref)",
+           "note": "cells listed in `edge_ub` have a bounding box clamped onto the far map edge: the reference then walks the "
+                   "non-existent row/column `size` through an uninitialised Position (undefined behaviour) — excluded from parity",
+           "cases": []}
+    for geom, sig, th, index in (((6.0, 4.0, 0.2, 3.0, 0.0), (0.16, 0.16, 0.017), 0.3, 0),
+                                 ((6.0, 4.0, 0.2, 3.0, 0.0), (0.005, 0.005, 0.0125), -1.2, 7),
+                                 ((5.0, 3.0, 0.1, 1.0, -0.5), (0.05, 0.08, 0.03), 2.5, 0),
+                                 ((6.0, 4.0, 0.2, 2.0, 0.0), (0.3, 0.2, 0.05), 0.9, 0)):
+        g = O.map_geom(*geom)
+        src = rng.integers(0, 101, (g.rows, g.cols)).astype(np.float32)
+        src[rng.random(src.shape) < 0.02] = np.nan
+        ro, rc, ell = O.ref_blur(src, geom, np.sin(th), np.cos(th), *sig, index=index)
+        oo, oc, _ = O.blur(src, g, np.sin(th), np.cos(th), *sig, index=index)
+        edge = np.nonzero(rc != oc)[0]
+
+        def enc(a):
+            return [None if not np.isfinite(v) else float(v) for v in np.asarray(a).flatten(order="F")]
+        out["cases"].append(dict(geom=list(geom), sigma=list(sig), theta=th, index=index, shape=[g.rows, g.cols], src=enc(src),
+                                 out=enc(ro), count=rc.tolist(), ellipse=[[None if not np.isfinite(v) else float(v) for v in e] for e in ell],
+                                 edge_ub=edge.tolist()))
+    dump("ref_blur.json", out)
+
+
 if __name__ == "__main__":
     O.build(ref=True)
     gen_survey()
@@ -214,4 +240,5 @@ if __name__ == "__main__":
     gen_quu()
     gen_polyfit()
     gen_gridmap()
+    gen_blur()
     gen_oracle_solves()

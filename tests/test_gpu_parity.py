@@ -329,3 +329,54 @@ def test_automatic_family_choice_large_batch(cilqr, oracle):
     want = _oracle_batch(oracle, 50, sub)
     _compare({k: v[:256] for k, v in got.items()}, want, TIGHT, "auto G")
     assert np.isfinite(got["U"]).all()
+
+
+# ------------------------------------------------------------------------------------------------ uncertainty blur
+def _ulp32_diff(a, b):
+    """Distance in float32 ulps between same-shaped arrays; NaN pairs count as 0, NaN vs number as huge."""
+    ai = a.view(np.int32).astype(np.int64)
+    bi = b.view(np.int32).astype(np.int64)
+    ai = np.where(ai < 0, -(ai & 0x7fffffff), ai)
+    bi = np.where(bi < 0, -(bi & 0x7fffffff), bi)
+    d = np.abs(ai - bi)
+    both_nan = np.isnan(a) & np.isnan(b)
+    one_nan = np.isnan(a) ^ np.isnan(b)
+    return np.where(both_nan, 0, np.where(one_nan, 1 << 40, d))
+
+
+@pytest.mark.parametrize("geom,sigma,theta,index", [
+    ((30.0, 20.0, 0.2, 15.0, 0.0), (0.16, 0.16, 0.017), -1.2, 0),      # the node's default vehicle map, launch-file sigmas
+    ((30.0, 20.0, 0.2, 15.0, 0.0), (0.005, 0.005, 0.0125), 0.3, 40),   # dynamic_reconfigure defaults: many NaN-axis cells
+    ((30.0, 20.0, 0.2, 10.0, 0.0), (0.3, 0.2, 0.05), 2.5, 0),          # large ellipses (up to ~370 cells)
+    ((51.2, 51.2, 0.1, 5.0, -3.0), (0.16, 0.16, 0.017), 0.9, 0),       # 512 × 512 cells
+])
+def test_blur_kernel_vs_oracle(cilqr, oracle, solver, geom, sigma, theta, index):
+    """Fused blur kernel against the oracle (itself bit-equal to the reference's grid_map_core + Eigen, tests/test_oracle.py).
+    Tolerance: ellipse membership counts EQUAL; outputs within 1 float32 ulp (the density uses hoisted reciprocals:
+    ~1e-16 relative in fp64 before the final cast), at least 99.9 % of them bit-equal."""
+    rng = np.random.default_rng(31)
+    g, og = cilqr.map_geom(*geom), oracle.map_geom(*geom)
+    src = rng.integers(0, 101, (g.rows, g.cols)).astype(np.float32)
+    src[rng.random(src.shape) < 0.01] = np.nan
+    got, cnt = solver.blur_costmap(src, g, theta, *sigma, index=index)
+    want, wcnt, _ = oracle.blur(src, og, np.sin(theta), np.cos(theta), *sigma, index=index, threads=16)
+    assert np.array_equal(cnt[index:], wcnt[index:])
+    d = _ulp32_diff(np.ascontiguousarray(got.flatten(order="F")), np.ascontiguousarray(want.flatten(order="F")))
+    assert d.max() <= 1, d.max()
+    assert (d == 0).mean() >= 0.999
+    assert np.isnan(got.flatten(order="F")[:index]).all()
+
+
+def test_blur_kernel_vs_reference_golden(cilqr, solver):
+    for c in load_golden("ref_blur.json")["cases"]:
+        shape = c["shape"]
+        src = np.array([np.nan if v is None else v for v in c["src"]], dtype=np.float32).reshape(shape, order="F")
+        want = np.array([np.nan if v is None else v for v in c["out"]], dtype=np.float32).reshape(shape, order="F")
+        g = cilqr.map_geom(*c["geom"])
+        got, cnt = solver.blur_costmap(src, g, c["theta"], *c["sigma"], index=c["index"])
+        keep = np.ones(cnt.size, bool)
+        keep[c["edge_ub"]] = False
+        keep[:c["index"]] = False
+        assert np.array_equal(cnt[keep], np.array(c["count"])[keep])
+        d = _ulp32_diff(np.ascontiguousarray(got.flatten(order="F")), np.ascontiguousarray(want.flatten(order="F")))
+        assert d[keep].max() <= 1

@@ -20,7 +20,7 @@ EXIT_TOLERANCE, EXIT_LAMBDA_MAX, EXIT_MAX_ITER, EXIT_NUMERIC = 0, 1, 2, 3
 ABI_SYMBOLS = (
     "cilqr_params_default", "cilqr_abi_version", "cilqr_last_error", "cilqr_default_control_seq",
     "cilqr_local_plan", "cilqr_create", "cilqr_destroy", "cilqr_solve_batch", "cilqr_solve_batch_device",
-    "cilqr_argmin_device", "cilqr_wait", "cilqr_set_diag_buffer", "cilqr_debug_quu_inverse", "cilqr_warp_costmap", "cilqr_warp_costmap_device", "cilqr_map_geom_set",
+    "cilqr_argmin_device", "cilqr_wait", "cilqr_set_diag_buffer", "cilqr_debug_quu_inverse", "cilqr_warp_costmap", "cilqr_warp_costmap_device", "cilqr_blur_costmap", "cilqr_blur_costmap_device", "cilqr_map_geom_set",
 )
 
 _dp = C.POINTER(C.c_double)
@@ -210,3 +210,20 @@ class Solver:
         _check(lib().cilqr_warp_costmap_device(self._h, _vp(stream), _vp(src), C.byref(src_geom), _vp(dst),
                                                C.byref(dst_geom), C.c_double(vx), C.c_double(vy), C.c_double(vtheta),
                                                _vp(bbox), _vp(n_oob)))
+
+
+    def blur_costmap(self, src, geom, vtheta, sigma_x, sigma_y, sigma_theta, index=0):
+        """src: (rows, cols) float32.  Returns (out F-ordered float32, counts (rows*cols,) int32)."""
+        src = np.asfortranarray(src, dtype=np.float32)
+        assert src.shape == (geom.rows, geom.cols)
+        out = np.zeros((geom.rows, geom.cols), dtype=np.float32, order="F")
+        cnt = np.zeros(geom.rows * geom.cols, dtype=np.int32)
+        _check(lib().cilqr_blur_costmap(self._h, src.ctypes.data_as(_fp), C.byref(geom), int(index), C.c_double(vtheta),
+                                        C.c_double(sigma_x), C.c_double(sigma_y), C.c_double(sigma_theta),
+                                        out.ctypes.data_as(_fp), cnt.ctypes.data_as(_ip)))
+        return out, cnt
+
+    def blur_costmap_device(self, stream, src, geom, vtheta, sigma_x, sigma_y, sigma_theta, out, index=0, count_out=0):
+        _check(lib().cilqr_blur_costmap_device(self._h, _vp(stream), _vp(src), C.byref(geom), int(index), C.c_double(vtheta),
+                                               C.c_double(sigma_x), C.c_double(sigma_y), C.c_double(sigma_theta), _vp(out),
+                                               _vp(count_out)))

@@ -307,6 +307,52 @@ int cilqr_argmin_device(cilqr_handle* h, void* stream, int B, const double* J, d
   return CILQR_OK;
 }
 
+int cilqr_blur_costmap_device(cilqr_handle* h, void* stream, const float* src, const cilqr_map_geom* g, int index, double vtheta,
+                              double sigma_x, double sigma_y, double sigma_theta, float* out, int32_t* count_out) {
+  if (!h || !src || !g || !out) return fail(CILQR_ERR_ARG, "cilqr_blur_costmap: null argument");
+  if (g->rows < 1 || g->cols < 1 || !(g->res > 0.0) || index < 0) return fail(CILQR_ERR_ARG, "cilqr_blur_costmap: bad geometry");
+  HIP_TRY(hipSetDevice(h->device));
+  cilqr::BlurArgs a;
+  a.src = src; a.out = out; a.count_out = count_out;
+  a.g = *g; a.index = index;
+  a.sin_t = sin(vtheta);  // host libm, as the caller of the reference does (M/src/local_costmap.cpp:201-202)
+  a.cos_t = cos(vtheta);
+  a.sigma_x = sigma_x; a.sigma_y = sigma_y; a.sigma_theta = sigma_theta;
+  HIP_TRY(cilqr::launch_blur(a, (hipStream_t)stream));
+  return CILQR_OK;
+}
+
+int cilqr_blur_costmap(cilqr_handle* h, const float* src, const cilqr_map_geom* g, int index, double vtheta, double sigma_x,
+                       double sigma_y, double sigma_theta, float* out, int32_t* count_out) {
+  if (!h || !src || !g || !out) return fail(CILQR_ERR_ARG, "cilqr_blur_costmap: null argument");
+  if (g->rows < 1 || g->cols < 1) return fail(CILQR_ERR_ARG, "cilqr_blur_costmap: bad geometry");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t n = (size_t)g->rows * g->cols;
+  if (n > h->src_cap) {
+    if (h->d_src) HIP_TRY(hipFree(h->d_src));
+    h->d_src = nullptr; h->src_cap = 0;
+    HIP_TRY(dmalloc(&h->d_src, n));
+    h->src_cap = n;
+  }
+  if (n > h->dst_cap) {
+    if (h->d_dst) HIP_TRY(hipFree(h->d_dst));
+    h->d_dst = nullptr; h->dst_cap = 0;
+    HIP_TRY(dmalloc(&h->d_dst, n));
+    h->dst_cap = n;
+  }
+  int32_t* d_cnt = nullptr;
+  if (count_out) HIP_TRY(dmalloc(&d_cnt, n));
+  hipStream_t s = h->stream;
+  HIP_TRY(hipMemcpyAsync(h->d_src, src, n * sizeof(float), hipMemcpyHostToDevice, s));
+  int rc = cilqr_blur_costmap_device(h, s, h->d_src, g, index, vtheta, sigma_x, sigma_y, sigma_theta, h->d_dst, d_cnt);
+  if (rc) { if (d_cnt) (void)hipFree(d_cnt); return rc; }
+  HIP_TRY(hipMemcpyAsync(out, h->d_dst, n * sizeof(float), hipMemcpyDeviceToHost, s));
+  if (count_out) HIP_TRY(hipMemcpyAsync(count_out, d_cnt, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (d_cnt) (void)hipFree(d_cnt);
+  return CILQR_OK;
+}
+
 int cilqr_map_geom_set(cilqr_map_geom* g, double len_x, double len_y, double res, double pos_x, double pos_y) {
   if (!g || !(len_x > 0.0) || !(len_y > 0.0) || !(res > 0.0)) return fail(CILQR_ERR_ARG, "cilqr_map_geom_set: bad argument");
   // GridMap::setGeometry (G/grid_map_core/src/GridMap.cpp:45-62)

@@ -69,4 +69,14 @@ struct WarpArgs {
 };
 hipError_t launch_warp(const WarpArgs& a, hipStream_t stream);
 
+struct BlurArgs {
+  const float* src;
+  float* out;
+  int32_t* count_out;  // may be null
+  cilqr_map_geom g;
+  int32_t index;       // first linear cell index processed (cells before it are set NaN)
+  double sin_t, cos_t, sigma_x, sigma_y, sigma_theta;
+};
+hipError_t launch_blur(const BlurArgs& a, hipStream_t stream);
+
 }  // namespace cilqr
