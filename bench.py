@@ -112,13 +112,87 @@ def bench_warp(args, rank, local_rank, world, dist, dev):
         dist.destroy_process_group()
 
 
+def bench_blur(args, rank, local_rank, world, dist, dev):
+    """pose-uncertainty blur of the node's vehicle map.  Default size of the reference node (150 x 100 cells,
+    M/src/local_costmap.cpp:132) with the launch-file sigmas, or --batch S for an S x S map at 0.1 m."""
+    import cilqr_amd
+    S = args.batch
+    geom = (30.0, 20.0, 0.2, 15.0, 0.0) if not S else (S * 0.1, S * 0.1, 0.1, 5.0, -3.0)
+    sig = (0.16, 0.16, 0.017)
+    g = cilqr_amd.map_geom(*geom)
+    rng = np.random.default_rng(41 + rank)
+    src_h = rng.integers(0, 101, (g.rows, g.cols)).astype(np.float32)
+    solver = cilqr_amd.Solver(cilqr_amd.default_params(), max_batch=1, max_horizon=1, max_obstacles=0, device=local_rank)
+    src = torch.from_numpy(np.ascontiguousarray(src_h.T)).to(dev)
+    out = torch.zeros(g.rows * g.cols, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(k, rec=False):
+        if rec:
+            ev0[k].record()
+        solver.blur_costmap_device(stream, src.data_ptr(), g, 0.3 + 0.01 * k, *sig, out.data_ptr())
+        if rec:
+            ev1[k].record()
+    for k in range(args.warmup):
+        step(k)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k, True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    if rank == 0:
+        cells = g.rows * g.cols
+        bytes_launch = 8 * cells
+        achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
+        outj = {"metric": "uncertainty-blur frames/sec (%dx%d cells)" % (g.rows, g.cols), "value": args.steps * world / elapsed,
+                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f64 (float eigen-solve), f32 payload", "data": "synthetic",
+                "config": {"workload": "SURVEY 8f-1: thrust_propagateUncertainty replacement, %dx%d cells, sigmas %s" % (g.rows, g.cols, sig)},
+                "roofline": {"bound": "hbm", "kernel": "blur_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms,
+                             "algorithmic_bytes_per_launch": bytes_launch,
+                             "note": "fp64-VALU-bound: ~20-400 tested cells and ~20-80 exp() per output cell"}}
+        if not args.no_cpu_baseline:
+            from oracle import oracle as O
+            O.build(ref=False)
+            threads = O.max_threads()
+            og = O.map_geom(*geom)
+            t1 = time.perf_counter()
+            want, wcnt, _ = O.blur(src_h, og, np.sin(0.3), np.cos(0.3), *sig, threads=threads)
+            cpu_s = time.perf_counter() - t1
+            solver.blur_costmap_device(stream, src.data_ptr(), g, 0.3, *sig, out.data_ptr())
+            torch.cuda.synchronize()
+            got = out.cpu().numpy().reshape(g.cols, g.rows).T
+            outj["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "frames/s", "cores": threads, "kind": "port", "sample": "one frame, OpenMP over cells"}
+            outj["max_abs_diff_vs_oracle"] = float(np.nanmax(np.abs(got - want)))
+        print(json.dumps(outj), flush=True)
+    solver.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=0, help="solves per GPU per step (default: the config's own size)")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "warp"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "warp", "blur"],
                     help="c2 (default, the config BASELINE.json's metric is quoted on): B=1024 N=50 M=4; c3: B=4096 N=50, 8x32 "
                          "sampled obstacles; c5: B=8192 per GPU N=80 M=16; warp: config 4, 1024x1024 costmap frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -146,6 +220,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     if args.workload == "warp":
         return bench_warp(args, rank, local_rank, world, dist, dev)
+    if args.workload == "blur":
+        return bench_blur(args, rank, local_rank, world, dist, dev)
     if args.workload == "c2":
         B, N, M = args.batch or 1024, 50, 4
         p = cilqr_amd.default_params(N)

@@ -195,6 +195,11 @@ int cilqr_set_diag_buffer(cilqr_handle* h, uint64_t* dev_buf);
  * reference's EigenSolver outputs (tests/golden/ref_quu.json) without having to provoke it through a whole solve. */
 int cilqr_debug_quu_inverse(cilqr_handle* h, int n, const double* Quu, const double* lamb, double* Qinv, int general);
 
+/* Test hook: the blur kernel's own covariance → confidence-ellipse step (float eigen-solve following Eigen::EigenSolver
+ * <Matrix2f>, M/src/arbitrary_transformation.cu:60-83 + M/include/ARBIT.cuh:82-99) on n covariances {a, b, c} (host buffers);
+ * out = {half_major, half_minor, angle} per row.  Checked bit for bit against the reference's Eigen (ref_blur.json). */
+int cilqr_debug_blur_ellipse(cilqr_handle* h, int n, const double* abc, double* out);
+
 /* Blocks until everything the host-pointer entry points enqueued on the handle's own stream has finished. */
 int cilqr_wait(cilqr_handle* h);
 

@@ -348,7 +348,7 @@ def _ulp32_diff(a, b):
     ((30.0, 20.0, 0.2, 15.0, 0.0), (0.16, 0.16, 0.017), -1.2, 0),      # the node's default vehicle map, launch-file sigmas
     ((30.0, 20.0, 0.2, 15.0, 0.0), (0.005, 0.005, 0.0125), 0.3, 40),   # dynamic_reconfigure defaults: many NaN-axis cells
     ((30.0, 20.0, 0.2, 10.0, 0.0), (0.3, 0.2, 0.05), 2.5, 0),          # large ellipses (up to ~370 cells)
-    ((51.2, 51.2, 0.1, 5.0, -3.0), (0.16, 0.16, 0.017), 0.9, 0),       # 512 × 512 cells
+    ((102.4, 102.4, 0.1, 5.0, -3.0), (0.16, 0.16, 0.017), 0.3, 0),     # 1024 × 1024 cells
 ])
 def test_blur_kernel_vs_oracle(cilqr, oracle, solver, geom, sigma, theta, index):
     """Fused blur kernel against the oracle (itself bit-equal to the reference's grid_map_core + Eigen, tests/test_oracle.py).
@@ -380,3 +380,28 @@ def test_blur_kernel_vs_reference_golden(cilqr, solver):
         assert np.array_equal(cnt[keep], np.array(c["count"])[keep])
         d = _ulp32_diff(np.ascontiguousarray(got.flatten(order="F")), np.ascontiguousarray(want.flatten(order="F")))
         assert d[keep].max() <= 1
+
+
+def test_blur_ellipse_step_vs_reference_eigen(cilqr, solver):
+    """The kernel's covariance → confidence-ellipse step (float eigen-solve) against the values the reference's own
+    Eigen::EigenSolver<Matrix2f> produced (ref_blur.json): half axes bit-equal (NaN where the reference has NaN — slightly
+    negative float eigenvalues), angle within 4 double ulps (atan2 of identical float inputs, different libm)."""
+    for c in load_golden("ref_blur.json")["cases"]:
+        g = cilqr.map_geom(*c["geom"])
+        lin = np.arange(c["index"], g.rows * g.cols)
+        ci, cj = lin % g.rows, lin // g.rows
+        Cx = (g.pos_x + (0.5 * g.len_x - 0.5 * g.res)) + g.res * (-ci.astype(float))
+        Cy = (g.pos_y + (0.5 * g.len_y - 0.5 * g.res)) + g.res * (-cj.astype(float))
+        s, co = np.sin(c["theta"]), np.cos(c["theta"])
+        sx, sy, st = c["sigma"]
+        u = (-s * Cx - co * Cy) * (-s * Cx - co * Cy)
+        v = (co * Cx - s * Cy) * (co * Cx - s * Cy)
+        t = s * co * (Cx * Cx - Cy * Cy) + Cx * Cy * (s * s - co * co)
+        sxi, syi = np.sqrt(sx * sx + st * st * u), np.sqrt(sy * sy + st * st * v)
+        rho = st * st * t / (sxi * syi)
+        got = solver.debug_blur_ellipse(np.stack([sxi * sxi, rho * sxi * syi, syi * syi], 1))
+        want = np.array([[np.nan if x is None else x for x in c["ellipse"][k]] for k in lin])
+        assert np.array_equal(got[:, :2], want[:, :2], equal_nan=True)
+        ok = np.isfinite(want[:, 2])
+        assert np.max(np.abs(got[ok, 2] - want[ok, 2]) / np.spacing(np.abs(want[ok, 2]))) <= 4
+        assert np.isnan(want[:, 1]).sum() == np.isnan(got[:, 1]).sum()

@@ -20,7 +20,7 @@ EXIT_TOLERANCE, EXIT_LAMBDA_MAX, EXIT_MAX_ITER, EXIT_NUMERIC = 0, 1, 2, 3
 ABI_SYMBOLS = (
     "cilqr_params_default", "cilqr_abi_version", "cilqr_last_error", "cilqr_default_control_seq",
     "cilqr_local_plan", "cilqr_create", "cilqr_destroy", "cilqr_solve_batch", "cilqr_solve_batch_device",
-    "cilqr_argmin_device", "cilqr_wait", "cilqr_set_diag_buffer", "cilqr_debug_quu_inverse", "cilqr_warp_costmap", "cilqr_warp_costmap_device", "cilqr_blur_costmap", "cilqr_blur_costmap_device", "cilqr_map_geom_set",
+    "cilqr_argmin_device", "cilqr_wait", "cilqr_set_diag_buffer", "cilqr_debug_quu_inverse", "cilqr_debug_blur_ellipse", "cilqr_warp_costmap", "cilqr_warp_costmap_device", "cilqr_blur_costmap", "cilqr_blur_costmap_device", "cilqr_map_geom_set",
 )
 
 _dp = C.POINTER(C.c_double)
@@ -184,6 +184,12 @@ class Solver:
         lamb = _np64(lamb).reshape(-1)
         out = np.zeros_like(Quu)
         _check(lib().cilqr_debug_quu_inverse(self._h, int(Quu.shape[0]), _p(Quu), _p(lamb), _p(out), int(bool(general))))
+        return out
+
+    def debug_blur_ellipse(self, abc):
+        abc = _np64(abc).reshape(-1, 3)
+        out = np.zeros_like(abc)
+        _check(lib().cilqr_debug_blur_ellipse(self._h, int(abc.shape[0]), _p(abc), _p(out)))
         return out
 
     def wait(self):

@@ -228,6 +228,20 @@ int cilqr_debug_quu_inverse(cilqr_handle* h, int n, const double* Quu, const dou
   return CILQR_OK;
 }
 
+int cilqr_debug_blur_ellipse(cilqr_handle* h, int n, const double* abc, double* out) {
+  if (!h || n < 1 || !abc || !out) return fail(CILQR_ERR_ARG, "cilqr_debug_blur_ellipse: bad argument");
+  HIP_TRY(hipSetDevice(h->device));
+  double *d_in = nullptr, *d_out = nullptr;
+  HIP_TRY(dmalloc(&d_in, (size_t)3 * n));
+  HIP_TRY(dmalloc(&d_out, (size_t)3 * n));
+  HIP_TRY(hipMemcpy(d_in, abc, sizeof(double) * 3 * n, hipMemcpyHostToDevice));
+  HIP_TRY(cilqr::launch_blur_ellipse(n, d_in, d_out, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(out, d_out, sizeof(double) * 3 * n, hipMemcpyDeviceToHost));
+  (void)hipFree(d_in); (void)hipFree(d_out);
+  return CILQR_OK;
+}
+
 int cilqr_wait(cilqr_handle* h) {
   if (!h) return fail(CILQR_ERR_ARG, "null handle");
   HIP_TRY(hipStreamSynchronize(h->stream));

@@ -78,5 +78,6 @@ struct BlurArgs {
   double sin_t, cos_t, sigma_x, sigma_y, sigma_theta;
 };
 hipError_t launch_blur(const BlurArgs& a, hipStream_t stream);
+hipError_t launch_blur_ellipse(int n, const double* abc, double* out, hipStream_t stream);
 
 }  // namespace cilqr

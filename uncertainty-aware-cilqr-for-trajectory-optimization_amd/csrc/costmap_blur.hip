@@ -30,6 +30,10 @@ struct Ellipse {
   double half_major, half_minor, angle;
 };
 
+// Correctly rounded float square root.  v_sqrt_f32 is a 1-ulp instruction and hipcc emits it bare for sqrtf/__fsqrt_rn; the
+// fp64 square root is correctly rounded, and rounding it to float is again correctly rounded (53 ≥ 2·24 + 2).
+__device__ __forceinline__ float sqrt_f32_rn(float x) { return (float)sqrt((double)x); }
+
 // Eigen::EigenSolver<Matrix2f> on [[a,b],[b,c]] → pseudoEigenvalueMatrix / pseudoEigenvectors → ellipse parameters
 // (M/src/arbitrary_transformation.cu:60-83, ARBIT.cuh:82-99; Eigen 3.2.10 RealSchur.h:246-392, EigenSolver.h:370-600).
 __device__ __forceinline__ Ellipse ellipse_from_cov(double a, double b, double c) {
@@ -47,19 +51,19 @@ __device__ __forceinline__ Ellipse ellipse_from_cov(double a, double b, double c
       const float pp = 0.5f * (t00 - t11);
       const float q = pp * pp + t10 * t01;
       if (q >= 0.f) {
-        const float z = __fsqrt_rn(fabsf(q));
+        const float z = sqrt_f32_rn(fabsf(q));
         const float gp = (pp >= 0.f) ? pp + z : pp - z, gq = t10;
         float cc, sn;
         if (gq == 0.f) { cc = gp < 0.f ? -1.f : 1.f; sn = 0.f; }
         else if (gp == 0.f) { cc = 0.f; sn = gq < 0.f ? 1.f : -1.f; }
         else if (fabsf(gp) > fabsf(gq)) {
           const float tt = __fdiv_rn(gq, gp);
-          float uu = __fsqrt_rn(1.f + tt * tt);
+          float uu = sqrt_f32_rn(1.f + tt * tt);
           if (gp < 0.f) uu = -uu;
           cc = __fdiv_rn(1.f, uu); sn = -tt * cc;
         } else {
           const float tt = __fdiv_rn(gp, gq);
-          float uu = __fsqrt_rn(1.f + tt * tt);
+          float uu = sqrt_f32_rn(1.f + tt * tt);
           if (gq < 0.f) uu = -uu;
           sn = __fdiv_rn(-1.f, uu); cc = -tt * sn;
         }
@@ -107,6 +111,19 @@ __device__ __forceinline__ Ellipse ellipse_from_cov(double a, double b, double c
   return e;
 }
 
+// Per-cell pose-uncertainty covariance and its confidence ellipse.
+__device__ __forceinline__ Ellipse cell_ellipse(const BlurArgs& a, double Cx, double Cy, double& sxi, double& syi, double& rho) {
+#pragma clang fp contract(off)
+  const double s = a.sin_t, c = a.cos_t;
+  const double u = (-s * Cx - c * Cy) * (-s * Cx - c * Cy);
+  const double v = (c * Cx - s * Cy) * (c * Cx - s * Cy);
+  const double t = s * c * (Cx * Cx - Cy * Cy) + Cx * Cy * (s * s - c * c);
+  sxi = sqrt(a.sigma_x * a.sigma_x + a.sigma_theta * a.sigma_theta * u);
+  syi = sqrt(a.sigma_y * a.sigma_y + a.sigma_theta * a.sigma_theta * v);
+  rho = a.sigma_theta * a.sigma_theta * t / (sxi * syi);
+  return ellipse_from_cov(sxi * sxi, rho * sxi * syi, syi * syi);
+}
+
 // boundPositionToRange, one axis (G/grid_map_core/src/GridMapMath.cpp:240-263)
 __device__ __forceinline__ double bound_axis(double position, double map_len, double map_pos) {
 #pragma clang fp contract(off)
@@ -142,15 +159,10 @@ __global__ __launch_bounds__(256) void blur_kernel(BlurArgs a) {
   const double Cx = x_first + res * (double)(-ci), Cy = y_first + res * (double)(-cj);
   const double s = a.sin_t, c = a.cos_t;
 
-  // uncertainty_error_functor / abc_functor (ARBIT.cuh:59-79)
-  const double ru = -s * Cx - c * Cy, rv = c * Cx - s * Cy;
-  const double u = ru * ru, v = rv * rv;
-  const double t = s * c * (Cx * Cx - Cy * Cy) + Cx * Cy * (s * s - c * c);
-  const double st2 = a.sigma_theta * a.sigma_theta;
-  const double sxi = sqrt(a.sigma_x * a.sigma_x + st2 * u);
-  const double syi = sqrt(a.sigma_y * a.sigma_y + st2 * v);
-  const double rho = st2 * t / (sxi * syi);
-  const Ellipse el = ellipse_from_cov(sxi * sxi, rho * sxi * syi, syi * syi);
+  // uncertainty_error_functor / abc_functor (ARBIT.cuh:59-79), contraction off: a, b, c feed a FLOAT eigen-solve whose
+  // outcome (which eigenvalue is the major one, the orientation of a near-circular ellipse) can hinge on their last bit
+  double sxi, syi, rho;
+  const Ellipse el = cell_ellipse(a, Cx, Cy, sxi, syi, rho);
 
   double numerator = 0.0, denominator = 0.0;
   int count = 0;
@@ -193,6 +205,21 @@ __global__ __launch_bounds__(256) void blur_kernel(BlurArgs a) {
 }
 
 }  // namespace
+
+namespace {
+__global__ void blur_ellipse_kernel(int n, const double* abc, double* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Ellipse e = ellipse_from_cov(abc[3 * i], abc[3 * i + 1], abc[3 * i + 2]);
+  out[3 * i] = e.half_major; out[3 * i + 1] = e.half_minor; out[3 * i + 2] = e.angle;
+}
+}  // namespace
+
+hipError_t launch_blur_ellipse(int n, const double* abc, double* out, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(blur_ellipse_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, abc, out);
+  return hipGetLastError();
+}
 
 hipError_t launch_blur(const BlurArgs& a, hipStream_t stream) {
   const long n = (long)a.g.rows * a.g.cols;
