@@ -28,6 +28,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (cannot be collected inside this process): FETCH_SIZE
+# doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950, plus WRITE_SIZE.  Keyed by (workload, batch).
+PMC_TRAFFIC_BYTES = {("c2", 1024): 2 * 5645.43e3 + 2560e3}
 FP64_VALU_PEAK_TF = 78.6   # vector fp64 = half the 157.3 TF fp32 vector peak of MI355X_MICROARCH.md
 
 
@@ -56,7 +59,7 @@ def bench_warp(args, rank, local_rank, world, dist, dev):
         vx, vy, th = poses[(k + 7 * rank) % len(poses)]
         if rec:
             ev0[k].record()
-        solver.warp_costmap_device(stream, src.data_ptr(), sg, dst.data_ptr(), dg, vx, vy, th, 0, oob.data_ptr())
+        solver.warp_costmap_device(stream, src.data_ptr(), sg, dst.data_ptr(), dg, vx, vy, th, 0, 0)  # no out-of-range counter
         if rec:
             ev1[k].record()
     for k in range(args.warmup):
@@ -87,7 +90,7 @@ def bench_warp(args, rank, local_rank, world, dist, dev):
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 payload / f64 index math",
                "data": "synthetic",
                "config": {"workload": "BASELINE config 4: 1024x1024 occupancy costmap warp, one frame per step, maps resident in HBM"},
-               "roofline": {"bound": "hbm", "kernel": "warp_kernel (+ 8-byte counter memset)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+               "roofline": {"bound": "hbm", "kernel": "warp_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms,
                             "algorithmic_bytes_per_launch": bytes_launch}}
         if not args.no_cpu_baseline:
@@ -306,7 +309,9 @@ def main():
                        "batch_per_gpu": B, "horizon": N, "obstacles": M, "mean_reference_iterations": mean_iters,
                        "parallelism": "scene-sharded x%d, RCCL all-gather of (J,index)" % world},
             "roofline": {"bound": "hbm", "kernel": "cilqr_solve_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC_BYTES.get((args.workload, B)),
+                         "traffic_source": "profiles/r01_v4_solve_c2_summary.md (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+                         if (args.workload, B) in PMC_TRAFFIC_BYTES else None,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch,
                          "note": "latency/fp64-VALU-bound path: HBM fraction is tiny by design (LDS-resident solve); see fp64_valu"},
             "fp64_valu": {"achieved_tflops_est": flops_solve * B / (kern_ms * 1e-3) / 1e12, "peak_tflops": FP64_VALU_PEAK_TF,

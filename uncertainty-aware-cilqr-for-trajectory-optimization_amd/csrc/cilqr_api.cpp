@@ -272,7 +272,9 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
   int G = 64;
   if (h->force_g == 1 || h->force_g == 2 || h->force_g == 4 || h->force_g == 8 || h->force_g == 16 || h->force_g == 32 || h->force_g == 64) {
     G = h->force_g;
-  } else if (B > 2048) {
+  } else if (B > 2048 && M <= 32) {
+    // (with hundreds of obstacle entries per step the solve is a stream over its obstacle table: the wavefront-per-solve
+    // family reads it as whole 400-640 B rows per instruction and measures ≈2x faster there — BASELINE config 3)
     G = 32;
     while (G > 1 && (long)G * B > 65536) G >>= 1;
   }
