@@ -157,7 +157,6 @@ __global__ __launch_bounds__(256) void blur_kernel(BlurArgs a) {
   const double x_first = (a.g.pos_x + (0.5 * a.g.len_x - 0.5 * res));  // centre of cell row 0
   const double y_first = (a.g.pos_y + (0.5 * a.g.len_y - 0.5 * res));
   const double Cx = x_first + res * (double)(-ci), Cy = y_first + res * (double)(-cj);
-  const double s = a.sin_t, c = a.cos_t;
 
   // uncertainty_error_functor / abc_functor (ARBIT.cuh:59-79), contraction off: a, b, c feed a FLOAT eigen-solve whose
   // outcome (which eigenvalue is the major one, the orientation of a near-circular ellipse) can hinge on their last bit
