@@ -318,6 +318,16 @@ def main():
                           "flops_per_solve_est": flops_solve},
             "min_cost": {"J": best[0], "global_index": best[1]},
         }
+        # SURVEY §8(d) also asks for the host-buffer entry point (H2D + kernel + D2H); reported, never `value`
+        reps = 3 if M <= 16 else 1
+        hb = None
+        for _ in range(reps + 1):  # first call untimed
+            th = time.perf_counter()
+            solver.solve_batch(N, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"], sc["obs_weight"])
+            th = time.perf_counter() - th
+            hb = th if hb is None else min(hb, th)
+        out["host_buffer_api"] = {"value": B / hb, "unit": "solves/s", "ms_per_batch": 1e3 * hb,
+                                  "note": "cilqr_solve_batch from pageable host memory, PCIe copies included (best of %d)" % reps}
         if not args.no_cpu_baseline:
             from oracle import oracle as O
             O.build(ref=False)

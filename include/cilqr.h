@@ -15,7 +15,11 @@
  *   iLQR::get_optimal_control_seq       I/iLQR.cpp:201-245      cilqr_solve_batch / cilqr_solve_batch_device
  *   iLQR::set_Obstacle / clear_Obstacle I/iLQR.cpp:20-27        obs_* arguments of cilqr_solve_batch (M = 0 ⇒ cleared)
  *   Constraints::get_J                  I/Constraints.cpp:534-561   J_out of cilqr_solve_batch
- *   LocalPlanner::get_local_plan(_coeffs) I/LocalPlanner.cpp:25-117 cilqr_local_plan (host pre-step)
+ *   GridMapRosConverter::from/toOccupancyGrid G/grid_map_ros/src/GridMapRosConverter.cpp:225-307
+ *                                                                cilqr_occupancy_to_layer / cilqr_layer_to_occupancy(_device)
+ *   LocalCostmap::odomCallback (one frame) M/src/local_costmap.cpp:172-305 cilqr_costmap_frame_device
+ *   LocalPlanner::get_local_plan(_coeffs) I/LocalPlanner.cpp:25-117 cilqr_local_plan (host pre-step),
+ *                                                                cilqr_local_plan_batch(_device) (B candidates on the device)
  *   LocalCostmap::odomCallback warp loop M/src/local_costmap.cpp:242-264 cilqr_warp_costmap(_device)
  *   thrust_propagateUncertainty     M/src/arbitrary_transformation.cu:8-157  cilqr_blur_costmap(_device)
  *   (none: batch min-cost selection is new)      cilqr_argmin_device
@@ -143,6 +147,19 @@ int cilqr_default_control_seq(int N, double* U);
 int cilqr_local_plan(const cilqr_params* p, const double* path, int P, const double* ego_state,
                      double* coeffs, double* ref_traj, int* n_out);
 
+/* The same pre-step for B candidate ego poses at once, on the device, so that a batch solve can start
+ * from raw (global_path, ego): candidate b reads its 2×P column-major path at path + b*path_stride doubles
+ * (path_stride = 0: one path shared by all candidates, the reference's set_global_plan).  ego [B][4];
+ * outputs poly [B][6] (coefficients past poly_order are 0), xplan_fl [B][2] (first and last x of the slice, the two
+ * elements of x_local_plan the solve reads), ref_traj [B][2*num_of_local_wpts] or NULL (2×n column-major per candidate,
+ * the tail past n untouched), n_out [B] or NULL.  The fit is the host pre-step's, sum for sum; the Vandermonde entries are
+ * correctly rounded powers where the host uses libm's pow (see local_plan.hip).  Uses the handle's num_of_local_wpts and
+ * poly_order (≤ 5).  The *_device form takes device pointers and is asynchronous on `stream`. */
+int cilqr_local_plan_batch(cilqr_handle* h, int B, int P, const double* path, int64_t path_stride, const double* ego,
+                           double* poly, double* xplan_fl, double* ref_traj, int32_t* n_out);
+int cilqr_local_plan_batch_device(cilqr_handle* h, void* stream, int B, int P, const double* path, int64_t path_stride,
+                                  const double* ego, double* poly, double* xplan_fl, double* ref_traj, int32_t* n_out);
+
 /* --- solver ----------------------------------------------------------------------------------- */
 /* Sizes are upper bounds; device workspaces are allocated once here, never in solve. device = HIP
  * ordinal. */
@@ -228,6 +245,30 @@ int cilqr_blur_costmap(cilqr_handle* h, const float* src, const cilqr_map_geom* 
                        double sigma_y, double sigma_theta, float* out, int32_t* count_out);
 int cilqr_blur_costmap_device(cilqr_handle* h, void* stream, const float* src, const cilqr_map_geom* g, int index, double vtheta,
                               double sigma_x, double sigma_y, double sigma_theta, float* out, int32_t* count_out);
+
+/* --- wire formats either side of the costmap path --------------------------------- */
+/* GridMapRosConverter::fromOccupancyGrid's data loop (G/grid_map_ros/src/GridMapRosConverter.cpp:259-266, called at
+ * M/src/local_costmap.cpp:169): layer[i] = occ[n-1-i] == -1 ? NaN : (float)occ[n-1-i], i = column-major linear index.
+ * n_cells = width*height; the geometry side of the conversion is cilqr_map_geom_set(width*res, height*res, res,
+ * origin + length/2). */
+int cilqr_occupancy_to_layer(cilqr_handle* h, const int8_t* occ, int64_t n_cells, float* layer);
+int cilqr_occupancy_to_layer_device(cilqr_handle* h, void* stream, const int8_t* occ, int64_t n_cells, float* layer);
+/* GridMapRosConverter::toOccupancyGrid's data loop (:293-306, called at M/src/local_costmap.cpp:298 with range 0..100) for
+ * a layer whose circular-buffer start index is zero: v = (layer[i]-data_min)/(data_max-data_min) in float; NaN → -1, else
+ * the truncation of clamp(v,0,1)*100; stored at occ[n-1-i]. */
+int cilqr_layer_to_occupancy(cilqr_handle* h, const float* layer, int64_t n_cells, float data_min, float data_max, int8_t* occ);
+int cilqr_layer_to_occupancy_device(cilqr_handle* h, void* stream, const float* layer, int64_t n_cells, float data_min,
+                                    float data_max, int8_t* occ);
+
+/* One frame of the map node's odometry callback (M/src/local_costmap.cpp:172-305) on the device, asynchronous on `stream`:
+ * warp of the global layer into the vehicle frame with the optional bounding-box override (cilqr_warp_costmap_device) →
+ * pose-uncertainty blur (cilqr_blur_costmap_device, index 0) → the blurred layer as an OccupancyGrid with range 0..100
+ * written by the blur kernel itself.  vehicle_layer and uncertainty_layer (device, rows*cols floats each) receive the two
+ * float layers; occupancy_out (device, rows*cols int8) may be NULL. */
+int cilqr_costmap_frame_device(cilqr_handle* h, void* stream, const float* global_layer, const cilqr_map_geom* global_geom,
+                               const cilqr_map_geom* vehicle_geom, double vx, double vy, double vtheta, const float* bbox,
+                               double sigma_x, double sigma_y, double sigma_theta, float* vehicle_layer,
+                               float* uncertainty_layer, int8_t* occupancy_out, int64_t* n_out_of_range_dev);
 
 /* setGeometry(Length(lx,ly), res, Position(px,py)) size/length rule (G/grid_map_core/src/GridMap.cpp:45-62). */
 int cilqr_map_geom_set(cilqr_map_geom* g, double len_x, double len_y, double res, double pos_x, double pos_y);

@@ -101,6 +101,11 @@ void oracle_blur_ellipse(double a, double b, double c, double* half_major, doubl
 long oracle_blur(const float* src, const cilqr_map_geom* g, int index, double sin_t, double cos_t, double sigma_x,
                  double sigma_y, double sigma_theta, float* out, int* count_out, int threads);
 
+/* OccupancyGrid (int8, -1 = unknown) <-> grid_map float32 layer (NaN = unknown), cell order reversed
+ * (G/grid_map_ros/src/GridMapRosConverter.cpp:259-266 and :293-306); n = rows*cols; start index zero. */
+void oracle_occupancy_to_layer(const int8_t* occ, long n, float* layer);
+void oracle_layer_to_occupancy(const float* layer, long n, float data_min, float data_max, int8_t* occ);
+
 #ifdef __cplusplus
 }
 #endif

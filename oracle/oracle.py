@@ -187,6 +187,21 @@ def blur(src, g, sin_t, cos_t, sigma_x, sigma_y, sigma_theta, index=0, threads=1
     return out, cnt, int(n)
 
 
+def occupancy_to_layer(occ):
+    occ = np.ascontiguousarray(occ, dtype=np.int8).reshape(-1)
+    out = np.zeros(occ.size, dtype=np.float32)
+    lib().oracle_occupancy_to_layer(occ.ctypes.data_as(C.c_void_p), C.c_long(occ.size), out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def layer_to_occupancy(layer, data_min, data_max):
+    layer = np.ascontiguousarray(layer, dtype=np.float32).reshape(-1)
+    out = np.zeros(layer.size, dtype=np.int8)
+    lib().oracle_layer_to_occupancy(layer.ctypes.data_as(C.POINTER(C.c_float)), C.c_long(layer.size), C.c_float(data_min),
+                                    C.c_float(data_max), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 def ref_blur(src, geom_args, sin_t, cos_t, sigma_x, sigma_y, sigma_theta, index=0):
     """The same through the reference's own grid_map_core + Eigen (oracle/_ref); None when _ref is not built."""
     L = ref_lib("gridmap")

@@ -19,8 +19,10 @@ EXIT_TOLERANCE, EXIT_LAMBDA_MAX, EXIT_MAX_ITER, EXIT_NUMERIC = 0, 1, 2, 3
 # every symbol include/cilqr.h declares
 ABI_SYMBOLS = (
     "cilqr_params_default", "cilqr_abi_version", "cilqr_last_error", "cilqr_default_control_seq",
-    "cilqr_local_plan", "cilqr_create", "cilqr_destroy", "cilqr_solve_batch", "cilqr_solve_batch_device",
+    "cilqr_local_plan", "cilqr_local_plan_batch", "cilqr_local_plan_batch_device", "cilqr_create", "cilqr_destroy", "cilqr_solve_batch", "cilqr_solve_batch_device",
     "cilqr_argmin_device", "cilqr_wait", "cilqr_set_diag_buffer", "cilqr_debug_quu_inverse", "cilqr_debug_blur_ellipse", "cilqr_warp_costmap", "cilqr_warp_costmap_device", "cilqr_blur_costmap", "cilqr_blur_costmap_device", "cilqr_map_geom_set",
+    "cilqr_occupancy_to_layer", "cilqr_occupancy_to_layer_device", "cilqr_layer_to_occupancy", "cilqr_layer_to_occupancy_device",
+    "cilqr_costmap_frame_device",
 )
 
 _dp = C.POINTER(C.c_double)
@@ -173,6 +175,33 @@ class Solver:
                                               _vp(xplan_fl), _vp(obs_pose), _vp(obs_dim), _vp(obs_weight), _vp(X_out),
                                               _vp(J_out), _vp(iters_out), _vp(status_out), C.c_uint32(flags)))
 
+    # ---- batched LocalPlanner pre-step on the device ----
+    def local_plan_batch(self, path, ego):
+        """path: (P, 2) shared by all candidates, or (B, P, 2) one per candidate; ego: (B, 4).
+        Returns dict(poly (B,6), xplan_fl (B,2), ref_traj (B, W, 2), n (B,))."""
+        ego = _np64(ego).reshape(-1, 4)
+        B = ego.shape[0]
+        path = _np64(path)
+        if path.ndim == 3:
+            if path.shape[0] != B:
+                raise CilqrError("local_plan_batch: path batch dimension does not match ego")
+            P, stride = path.shape[1], 2 * path.shape[1]
+        else:
+            path = path.reshape(-1, 2)
+            P, stride = path.shape[0], 0
+        W = self.params.num_of_local_wpts
+        poly = np.zeros((B, POLY))
+        fl = np.zeros((B, 2))
+        ref = np.zeros((B, W, 2))
+        n = np.zeros(B, dtype=np.int32)
+        _check(lib().cilqr_local_plan_batch(self._h, B, int(P), _p(path), C.c_int64(stride), _p(ego), _p(poly), _p(fl), _p(ref),
+                                            _p(n, _ip)))
+        return dict(poly=poly, xplan_fl=fl, ref_traj=ref, n=n)
+
+    def local_plan_batch_device(self, stream, B, P, path, path_stride, ego, poly, xplan_fl, ref_traj=0, n_out=0):
+        _check(lib().cilqr_local_plan_batch_device(self._h, _vp(stream), int(B), int(P), _vp(path), C.c_int64(path_stride), _vp(ego),
+                                                   _vp(poly), _vp(xplan_fl), _vp(ref_traj), _vp(n_out)))
+
     def argmin_device(self, stream, B, J, out_pair):
         _check(lib().cilqr_argmin_device(self._h, _vp(stream), int(B), _vp(J), _vp(out_pair)))
 
@@ -228,6 +257,34 @@ class Solver:
                                         C.c_double(sigma_x), C.c_double(sigma_y), C.c_double(sigma_theta),
                                         out.ctypes.data_as(_fp), cnt.ctypes.data_as(_ip)))
         return out, cnt
+
+    # ---- OccupancyGrid <-> layer ----
+    def occupancy_to_layer(self, occ):
+        occ = np.ascontiguousarray(occ, dtype=np.int8).reshape(-1)
+        out = np.zeros(occ.size, dtype=np.float32)
+        _check(lib().cilqr_occupancy_to_layer(self._h, occ.ctypes.data_as(C.c_void_p), C.c_int64(occ.size), _p(out, _fp)))
+        return out
+
+    def layer_to_occupancy(self, layer, data_min, data_max):
+        layer = np.ascontiguousarray(layer, dtype=np.float32).reshape(-1)
+        out = np.zeros(layer.size, dtype=np.int8)
+        _check(lib().cilqr_layer_to_occupancy(self._h, _p(layer, _fp), C.c_int64(layer.size), C.c_float(data_min),
+                                              C.c_float(data_max), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def occupancy_to_layer_device(self, stream, occ, n_cells, layer):
+        _check(lib().cilqr_occupancy_to_layer_device(self._h, _vp(stream), _vp(occ), C.c_int64(n_cells), _vp(layer)))
+
+    def layer_to_occupancy_device(self, stream, layer, n_cells, data_min, data_max, occ):
+        _check(lib().cilqr_layer_to_occupancy_device(self._h, _vp(stream), _vp(layer), C.c_int64(n_cells), C.c_float(data_min),
+                                                     C.c_float(data_max), _vp(occ)))
+
+    def costmap_frame_device(self, stream, global_layer, global_geom, vehicle_geom, vx, vy, vtheta, sigma_x, sigma_y,
+                             sigma_theta, vehicle_layer, uncertainty_layer, occupancy_out=0, bbox=0, n_oob=0):
+        _check(lib().cilqr_costmap_frame_device(self._h, _vp(stream), _vp(global_layer), C.byref(global_geom),
+                                                C.byref(vehicle_geom), C.c_double(vx), C.c_double(vy), C.c_double(vtheta),
+                                                _vp(bbox), C.c_double(sigma_x), C.c_double(sigma_y), C.c_double(sigma_theta),
+                                                _vp(vehicle_layer), _vp(uncertainty_layer), _vp(occupancy_out), _vp(n_oob)))
 
     def blur_costmap_device(self, stream, src, geom, vtheta, sigma_x, sigma_y, sigma_theta, out, index=0, count_out=0):
         _check(lib().cilqr_blur_costmap_device(self._h, _vp(stream), _vp(src), C.byref(geom), int(index), C.c_double(vtheta),

@@ -330,6 +330,7 @@ int cilqr_blur_costmap_device(cilqr_handle* h, void* stream, const float* src, c
   HIP_TRY(hipSetDevice(h->device));
   cilqr::BlurArgs a;
   a.src = src; a.out = out; a.count_out = count_out;
+  a.occ_out = nullptr; a.occ_min = 0.0f; a.occ_den = 100.0f;
   a.g = *g; a.index = index;
   a.sin_t = sin(vtheta);  // host libm, as the caller of the reference does (M/src/local_costmap.cpp:201-202)
   a.cos_t = cos(vtheta);
@@ -366,6 +367,132 @@ int cilqr_blur_costmap(cilqr_handle* h, const float* src, const cilqr_map_geom* 
   if (count_out) HIP_TRY(hipMemcpyAsync(count_out, d_cnt, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   if (d_cnt) (void)hipFree(d_cnt);
+  return CILQR_OK;
+}
+
+int cilqr_local_plan_batch_device(cilqr_handle* h, void* stream, int B, int P, const double* path, int64_t path_stride,
+                                  const double* ego, double* poly, double* xplan_fl, double* ref_traj, int32_t* n_out) {
+  if (!h || !path || !ego || !poly || !xplan_fl) return fail(CILQR_ERR_ARG, "cilqr_local_plan_batch: null argument");
+  if (B < 1 || P < 1 || path_stride < 0) return fail(CILQR_ERR_ARG, "cilqr_local_plan_batch: bad size");
+  const cilqr_params& p = h->params;
+  if (p.num_of_local_wpts < 1 || p.poly_order < 0 || p.poly_order + 1 > CILQR_POLY_COEFFS)
+    return fail(CILQR_ERR_UNSUPPORTED, "cilqr_local_plan_batch: poly_order must be in [0, 5]");
+  if (cilqr::local_plan_lds_bytes(p.num_of_local_wpts, p.poly_order + 1) > 64 * 1024)
+    return fail(CILQR_ERR_UNSUPPORTED, "cilqr_local_plan_batch: num_of_local_wpts too large for the per-candidate LDS slot");
+  HIP_TRY(hipSetDevice(h->device));
+  cilqr::LocalPlanArgs a;
+  a.path = path; a.path_stride = path_stride; a.ego = ego;
+  a.poly = poly; a.xplan_fl = xplan_fl; a.ref_traj = ref_traj; a.n_out = n_out;
+  a.B = B; a.P = P; a.n_wpts = p.num_of_local_wpts; a.cols = p.poly_order + 1;
+  HIP_TRY(cilqr::launch_local_plan(a, (hipStream_t)stream));
+  return CILQR_OK;
+}
+
+int cilqr_local_plan_batch(cilqr_handle* h, int B, int P, const double* path, int64_t path_stride, const double* ego,
+                           double* poly, double* xplan_fl, double* ref_traj, int32_t* n_out) {
+  if (!h || !path || !ego || !poly || !xplan_fl) return fail(CILQR_ERR_ARG, "cilqr_local_plan_batch: null argument");
+  if (B < 1 || P < 1 || path_stride < 0) return fail(CILQR_ERR_ARG, "cilqr_local_plan_batch: bad size");
+  HIP_TRY(hipSetDevice(h->device));
+  const int W = h->params.num_of_local_wpts;
+  const size_t n_path = path_stride ? (size_t)(B - 1) * path_stride + 2 * (size_t)P : 2 * (size_t)P;
+  double *d_path = nullptr, *d_ego = nullptr, *d_poly = nullptr, *d_fl = nullptr, *d_ref = nullptr;
+  int32_t* d_n = nullptr;
+  auto release = [&]() {
+    (void)hipFree(d_path); (void)hipFree(d_ego); (void)hipFree(d_poly); (void)hipFree(d_fl); (void)hipFree(d_ref); (void)hipFree(d_n);
+  };
+  hipStream_t s = h->stream;
+  hipError_t e = dmalloc(&d_path, n_path);
+  if (e == hipSuccess) e = dmalloc(&d_ego, (size_t)B * 4);
+  if (e == hipSuccess) e = dmalloc(&d_poly, (size_t)B * CILQR_POLY_COEFFS);
+  if (e == hipSuccess) e = dmalloc(&d_fl, (size_t)B * 2);
+  if (e == hipSuccess && ref_traj) e = dmalloc(&d_ref, (size_t)B * 2 * W);
+  if (e == hipSuccess && n_out) e = dmalloc(&d_n, (size_t)B);
+  if (e == hipSuccess && ref_traj) e = hipMemsetAsync(d_ref, 0, (size_t)B * 2 * W * sizeof(double), s);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_path, path, n_path * sizeof(double), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_ego, ego, (size_t)B * 4 * sizeof(double), hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) { release(); HIP_TRY(e); }
+  const int rc = cilqr_local_plan_batch_device(h, s, B, P, d_path, path_stride, d_ego, d_poly, d_fl, d_ref, d_n);
+  if (rc) { release(); return rc; }
+  e = hipMemcpyAsync(poly, d_poly, (size_t)B * CILQR_POLY_COEFFS * sizeof(double), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(xplan_fl, d_fl, (size_t)B * 2 * sizeof(double), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess && ref_traj) e = hipMemcpyAsync(ref_traj, d_ref, (size_t)B * 2 * W * sizeof(double), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess && n_out) e = hipMemcpyAsync(n_out, d_n, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  release();
+  HIP_TRY(e);
+  return CILQR_OK;
+}
+
+int cilqr_occupancy_to_layer_device(cilqr_handle* h, void* stream, const int8_t* occ, int64_t n_cells, float* layer) {
+  if (!h || n_cells < 0 || (n_cells > 0 && (!occ || !layer))) return fail(CILQR_ERR_ARG, "cilqr_occupancy_to_layer: bad argument");
+  if (n_cells == 0) return CILQR_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(cilqr::launch_occ_to_layer(occ, layer, (long)n_cells, (hipStream_t)stream));
+  return CILQR_OK;
+}
+
+int cilqr_layer_to_occupancy_device(cilqr_handle* h, void* stream, const float* layer, int64_t n_cells, float data_min,
+                                    float data_max, int8_t* occ) {
+  if (!h || n_cells < 0 || (n_cells > 0 && (!occ || !layer))) return fail(CILQR_ERR_ARG, "cilqr_layer_to_occupancy: bad argument");
+  if (n_cells == 0) return CILQR_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(cilqr::launch_layer_to_occ(layer, occ, (long)n_cells, data_min, data_max, (hipStream_t)stream));
+  return CILQR_OK;
+}
+
+namespace {
+// host-buffer conversions: staged through scratch device buffers (convenience / test path, not a per-frame path)
+int convert_host(cilqr_handle* h, const void* in, size_t in_bytes, void* out, size_t out_bytes, bool to_layer, int64_t n, float lo, float hi) {
+  HIP_TRY(hipSetDevice(h->device));
+  if (n == 0) return CILQR_OK;
+  void *d_in = nullptr, *d_out = nullptr;
+  hipStream_t s = h->stream;
+  hipError_t e = hipMalloc(&d_in, in_bytes);
+  if (e == hipSuccess) e = hipMalloc(&d_out, out_bytes);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, s);
+  int rc = CILQR_OK;
+  if (e == hipSuccess)
+    rc = to_layer ? cilqr_occupancy_to_layer_device(h, s, (const int8_t*)d_in, n, (float*)d_out)
+                  : cilqr_layer_to_occupancy_device(h, s, (const float*)d_in, n, lo, hi, (int8_t*)d_out);
+  if (e == hipSuccess && rc == CILQR_OK) e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess && rc == CILQR_OK) e = hipStreamSynchronize(s);
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  if (rc) return rc;
+  HIP_TRY(e);
+  return CILQR_OK;
+}
+}  // namespace
+
+int cilqr_occupancy_to_layer(cilqr_handle* h, const int8_t* occ, int64_t n_cells, float* layer) {
+  if (!h || n_cells < 0 || (n_cells > 0 && (!occ || !layer))) return fail(CILQR_ERR_ARG, "cilqr_occupancy_to_layer: bad argument");
+  if (n_cells == 0) return CILQR_OK;
+  return convert_host(h, occ, (size_t)n_cells, layer, (size_t)n_cells * sizeof(float), true, n_cells, 0.f, 0.f);
+}
+
+int cilqr_layer_to_occupancy(cilqr_handle* h, const float* layer, int64_t n_cells, float data_min, float data_max, int8_t* occ) {
+  if (!h || n_cells < 0 || (n_cells > 0 && (!occ || !layer))) return fail(CILQR_ERR_ARG, "cilqr_layer_to_occupancy: bad argument");
+  if (n_cells == 0) return CILQR_OK;
+  return convert_host(h, layer, (size_t)n_cells * sizeof(float), occ, (size_t)n_cells, false, n_cells, data_min, data_max);
+}
+
+int cilqr_costmap_frame_device(cilqr_handle* h, void* stream, const float* global_layer, const cilqr_map_geom* global_geom,
+                               const cilqr_map_geom* vehicle_geom, double vx, double vy, double vtheta, const float* bbox,
+                               double sigma_x, double sigma_y, double sigma_theta, float* vehicle_layer,
+                               float* uncertainty_layer, int8_t* occupancy_out, int64_t* n_out_of_range_dev) {
+  if (!h || !global_layer || !global_geom || !vehicle_geom || !vehicle_layer || !uncertainty_layer)
+    return fail(CILQR_ERR_ARG, "cilqr_costmap_frame: null argument");
+  int rc = cilqr_warp_costmap_device(h, stream, global_layer, global_geom, vehicle_layer, vehicle_geom, vx, vy, vtheta, bbox,
+                                     n_out_of_range_dev);
+  if (rc) return rc;
+  if (vehicle_geom->rows < 1 || vehicle_geom->cols < 1 || !(vehicle_geom->res > 0.0)) return fail(CILQR_ERR_ARG, "cilqr_costmap_frame: bad geometry");
+  cilqr::BlurArgs a;
+  a.src = vehicle_layer; a.out = uncertainty_layer; a.count_out = nullptr;
+  a.occ_out = occupancy_out; a.occ_min = 0.0f; a.occ_den = 100.0f - 0.0f;  // toOccupancyGrid(..., 0, 100, ...) (M/src/local_costmap.cpp:298)
+  a.g = *vehicle_geom; a.index = 0;
+  a.sin_t = sin(vtheta); a.cos_t = cos(vtheta);
+  a.sigma_x = sigma_x; a.sigma_y = sigma_y; a.sigma_theta = sigma_theta;
+  HIP_TRY(cilqr::launch_blur(a, (hipStream_t)stream));
   return CILQR_OK;
 }
 

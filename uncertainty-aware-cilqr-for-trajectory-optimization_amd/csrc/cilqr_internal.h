@@ -56,6 +56,20 @@ hipError_t launch_solve_groups(const SolveArgs& a, int G, double* ws, hipStream_
 size_t solve_groups_ws_doubles(int B, int N);
 hipError_t launch_quu_inverse(int n, const double* q, const double* lamb, double* out, int general, hipStream_t stream);
 
+// Batched LocalPlanner (local_plan.hip): one lane per candidate.
+struct LocalPlanArgs {
+  const double* path;      // 2×P column-major; candidate b reads path + b*path_stride (0: one shared path)
+  long long path_stride;   // in doubles
+  const double* ego;       // [B][4]
+  double* poly;            // [B][6]
+  double* xplan_fl;        // [B][2]
+  double* ref_traj;        // null or [B][2*n_wpts]
+  int32_t* n_out;          // null or [B]
+  int32_t B, P, n_wpts, cols;
+};
+hipError_t launch_local_plan(const LocalPlanArgs& a, hipStream_t stream);
+size_t local_plan_lds_bytes(int n_wpts, int cols);
+
 hipError_t launch_argmin(const double* J, int B, double* out_pair, double* scratch, hipStream_t stream);
 size_t argmin_scratch_doubles(int B);
 
@@ -73,11 +87,16 @@ struct BlurArgs {
   const float* src;
   float* out;
   int32_t* count_out;  // may be null
+  int8_t* occ_out;     // may be null: the same cells as an OccupancyGrid (toOccupancyGrid of `out`, reversed order)
+  float occ_min, occ_den;  // dataMin and dataMax - dataMin of that conversion
   cilqr_map_geom g;
   int32_t index;       // first linear cell index processed (cells before it are set NaN)
   double sin_t, cos_t, sigma_x, sigma_y, sigma_theta;
 };
 hipError_t launch_blur(const BlurArgs& a, hipStream_t stream);
+// OccupancyGrid <-> layer (costmap_occupancy.hip)
+hipError_t launch_occ_to_layer(const int8_t* occ, float* layer, long n, hipStream_t stream);
+hipError_t launch_layer_to_occ(const float* layer, int8_t* occ, long n, float data_min, float data_max, hipStream_t stream);
 hipError_t launch_blur_ellipse(int n, const double* abc, double* out, hipStream_t stream);
 
 }  // namespace cilqr

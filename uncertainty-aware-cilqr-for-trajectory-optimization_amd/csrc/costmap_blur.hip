@@ -21,6 +21,7 @@
 #include <float.h>
 
 #include "cilqr_internal.h"
+#include "costmap_cells.hpp"
 
 namespace cilqr {
 
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(256) void blur_kernel(BlurArgs a) {
   if (lin >= n) return;
   if (lin < a.index) {
     a.out[lin] = __builtin_nanf("");  // never written by the reference (layer cleared by setGeometry)
+    if (a.occ_out) a.occ_out[n - 1 - lin] = (int8_t)-1;
     return;
   }
   const int rows = a.g.rows, cols = a.g.cols;
@@ -199,7 +201,10 @@ __global__ __launch_bounds__(256) void blur_kernel(BlurArgs a) {
       }
     }
   }
-  a.out[lin] = count == 0 ? a.src[lin] : (float)(numerator / denominator);  // local_costmap.cpp:489-496
+  const float blurred = count == 0 ? a.src[lin] : (float)(numerator / denominator);  // local_costmap.cpp:489-496
+  a.out[lin] = blurred;
+  // fused GridMapRosConverter::toOccupancyGrid of this layer (M/src/local_costmap.cpp:298), cell order reversed
+  if (a.occ_out) a.occ_out[n - 1 - lin] = layer_to_cell(blurred, a.occ_min, a.occ_den);
   if (a.count_out) a.count_out[lin] = count;
 }
 

@@ -103,19 +103,16 @@ int iLQR::run_candidates(const std::vector<double>& ego_states) {
   if (B < 1 || B > max_candidates_) throw std::runtime_error("run_candidates: candidate count outside [1, max_candidates]");
   if (global_plan_.cols < 1) throw std::runtime_error("run_candidates: set_global_plan was not called");
   std::vector<double> U((size_t)B * 2 * N), poly((size_t)B * CILQR_POLY_COEFFS), fl((size_t)B * 2);
-  std::vector<double> X((size_t)B * 4 * (N + 1)), J(B), ref(2 * (size_t)params.num_of_local_wpts);
+  std::vector<double> X((size_t)B * 4 * (N + 1)), J(B);
   std::vector<int32_t> iters(B), status(B);
-  std::vector<Matrix> refs(B);
-  for (int b = 0; b < B; ++b) {
-    int n = 0;
-    check(cilqr_local_plan(&params, global_plan_.a.data(), global_plan_.cols, &ego_states[4 * b], &poly[(size_t)b * CILQR_POLY_COEFFS],
-                           ref.data(), &n), "cilqr_local_plan");
-    fl[2 * b] = ref[0];
-    fl[2 * b + 1] = ref[2 * (n - 1)];
-    refs[b] = Matrix(2, n);
-    for (int i = 0; i < n; ++i) { refs[b](0, i) = ref[2 * i]; refs[b](1, i) = ref[2 * i + 1]; }
+  // LocalPlanner pre-step for all candidates in one device launch (cilqr_local_plan_batch) instead of B host fits
+  const int W = params.num_of_local_wpts;
+  std::vector<double> ref((size_t)B * 2 * W);
+  std::vector<int32_t> n_ref(B);
+  check(cilqr_local_plan_batch(h_, B, global_plan_.cols, global_plan_.a.data(), 0, ego_states.data(), poly.data(), fl.data(),
+                               ref.data(), n_ref.data()), "cilqr_local_plan_batch");
+  for (int b = 0; b < B; ++b)
     for (int i = 0; i < 2 * N; ++i) U[(size_t)b * 2 * N + i] = control_seq_.a[i];
-  }
   pack_obstacles(B);
   check(cilqr_solve_batch(h_, B, N, M, ego_states.data(), U.data(), poly.data(), fl.data(), M ? obs_pose_.data() : nullptr,
                           M ? obs_dim_.data() : nullptr, nullptr, X.data(), J.data(), iters.data(), status.data(), CILQR_FLAG_NONE),
@@ -128,7 +125,8 @@ int iLQR::run_candidates(const std::vector<double>& ego_states) {
   for (int i = 0; i < 4 * (N + 1); ++i) X_result.a[i] = X[(size_t)best * 4 * (N + 1) + i];
   for (int i = 0; i < 2 * N; ++i) control_seq_.a[i] = U[(size_t)best * 2 * N + i];
   U_result = control_seq_;
-  ref_traj_result = refs[best];
+  ref_traj_result = Matrix(2, n_ref[best]);
+  for (int i = 0; i < 2 * n_ref[best]; ++i) ref_traj_result.a[i] = ref[(size_t)best * 2 * W + i];
   last_iterations = iters[best];
   last_exit = status[best];
   last_cost = J[best];
