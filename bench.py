@@ -189,13 +189,215 @@ def bench_blur(args, rank, local_rank, world, dist, dev):
         dist.destroy_process_group()
 
 
+def _timed(step, args, dist, dev):
+    """Warm-up, then args.steps timed steps bracketed by barrier + synchronize; returns (max-over-ranks seconds, mean of the
+    HIP-event durations the step recorded around its dominant kernel, in ms)."""
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    for k in range(args.warmup):
+        step(k, None, None)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k, ev0[k], ev1[k])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+
+
+def _line(metric, unit, value, args, world, elapsed, dtype, workload, roofline):
+    return {"metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": dtype, "data": "synthetic", "config": {"workload": workload}, "roofline": roofline}
+
+
+def bench_occ(args, rank, local_rank, world, dist, dev):
+    """OccupancyGrid -> layer -> OccupancyGrid on an S x S grid (default 8192: 67 M cells, 5 B per cell and
+    direction), both buffers resident in HBM.  A step = both conversions; the roofline figure is the layer->occupancy one."""
+    import cilqr_amd
+    S = args.batch or 8192
+    n = S * S
+    solver = cilqr_amd.Solver(cilqr_amd.default_params(), max_batch=1, max_horizon=1, max_obstacles=0, device=local_rank)
+    rng = np.random.default_rng(51 + rank)
+    occ_h = rng.integers(-1, 101, n, dtype=np.int8)
+    occ = torch.from_numpy(occ_h).to(dev)
+    layer = torch.zeros(n, dtype=torch.float32, device=dev)
+    back = torch.zeros(n, dtype=torch.int8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(k, e0, e1):
+        solver.occupancy_to_layer_device(stream, occ.data_ptr(), n, layer.data_ptr())
+        if e0 is not None:
+            e0.record()
+        solver.layer_to_occupancy_device(stream, layer.data_ptr(), n, -1.0, 100.0, back.data_ptr())
+        if e1 is not None:
+            e1.record()
+    elapsed, kern_ms = _timed(step, args, dist, dev)
+    if rank == 0:
+        bytes_launch = 5 * n
+        achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
+        out = _line("OccupancyGrid<->layer cells/sec (%dx%d, both directions per step)" % (S, S), "cells/s",
+                    n * args.steps * world / elapsed, args, world, elapsed, "i8 / f32",
+                    "SURVEY 8f-4: fromOccupancyGrid + toOccupancyGrid(-1, 100) round trip, %d cells, buffers resident in HBM" % n,
+                    {"bound": "hbm", "kernel": "layer_to_occ_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch})
+        out["round_trip_exact"] = bool(torch.equal(back, occ))
+        if not args.no_cpu_baseline:
+            from oracle import oracle as O
+            O.build(ref=False)
+            ns = min(n, 1 << 26)
+            t1 = time.perf_counter()
+            lay = O.occupancy_to_layer(occ_h[:ns])
+            O.layer_to_occupancy(lay, -1.0, 100.0)
+            cpu_s = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": ns / cpu_s, "unit": "cells/s", "cores": 1, "kind": "port",
+                                   "sample": "%d cells, both directions, scalar loops as in the reference" % ns}
+        print(json.dumps(out), flush=True)
+    solver.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def bench_frame(args, rank, local_rank, world, dist, dev):
+    """One frame of the map node's odometry callback per step (cilqr_costmap_frame_device: warp + bbox override -> blur ->
+    OccupancyGrid out).  Default: the node's own sizes (1506x1506 global map at 0.2 m, 150x100 vehicle map,
+    M/src/local_costmap.cpp:119,132); --batch S: config-4 shape, S x S vehicle map at 0.1 m out of a 1024x1024 source."""
+    import cilqr_amd
+    from cilqr_amd import scenes
+    S = args.batch
+    rng = np.random.default_rng(61 + rank)
+    if S:
+        c4 = scenes.make_c4()
+        sgeo, dgeo = c4["src_geom"], (S * 0.1, S * 0.1, 0.1, 0.0, 0.0)
+        src_h = c4["src"]
+        poses = [(vx, vy, th) for vx, vy, th in c4["poses"]]
+        shrink = S * 0.1 / c4["dst_geom"][0]
+        assert shrink <= 1.0, "--batch larger than config 4's 1024"
+    else:
+        sgeo, dgeo = (301.2, 301.2, 0.2, 0.0, 0.0), (30.0, 20.0, 0.2, 10.0 - 5, 0.0)
+        src_h = np.zeros((1506, 1506), dtype=np.float32)
+        for _ in range(400):
+            i, j = rng.integers(0, 1450, 2)
+            src_h[i:i + rng.integers(3, 50), j:j + rng.integers(3, 50)] = 100.0
+        src_h[rng.random(src_h.shape) < 0.02] = np.nan
+        poses = [(60 * np.cos(a), 60 * np.sin(a), a + np.pi / 2) for a in np.linspace(0, 2 * np.pi, 300, endpoint=False)]
+    sg, dg = cilqr_amd.map_geom(*sgeo), cilqr_amd.map_geom(*dgeo)
+    solver = cilqr_amd.Solver(cilqr_amd.default_params(), max_batch=1, max_horizon=1, max_obstacles=0, device=local_rank)
+    src = torch.from_numpy(np.ascontiguousarray(src_h.T)).to(dev)
+    nd = dg.rows * dg.cols
+    veh = torch.zeros(nd, dtype=torch.float32, device=dev)
+    unc = torch.zeros(nd, dtype=torch.float32, device=dev)
+    occ = torch.zeros(nd, dtype=torch.int8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    sig = (0.16, 0.16, 0.017)
+
+    def step(k, e0, e1):
+        vx, vy, th = poses[(k + 7 * rank) % len(poses)]
+        if e0 is not None:
+            e0.record()
+        solver.costmap_frame_device(stream, src.data_ptr(), sg, dg, vx, vy, th, *sig, veh.data_ptr(), unc.data_ptr(), occ.data_ptr())
+        if e1 is not None:
+            e1.record()
+    elapsed, kern_ms = _timed(step, args, dist, dev)
+    if rank == 0:
+        bytes_launch = 13 * nd  # warp: 4 read + 4 write; blur: 4 read (+ neighbours from cache) + 4 + 1 write
+        achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
+        out = _line("costmap frames/sec (warp + blur + OccupancyGrid, %dx%d vehicle map)" % (dg.rows, dg.cols), "frames/s",
+                    args.steps * world / elapsed, args, world, elapsed, "f64 index math and blur weights, f32 layers, i8 grid",
+                    "one odomCallback frame (M/src/local_costmap.cpp:172-305): %dx%d source -> %dx%d vehicle map, sigmas %s, maps "
+                    "resident in HBM" % (sg.rows, sg.cols, dg.rows, dg.cols, sig),
+                    {"bound": "hbm", "kernel": "warp_kernel + blur_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch,
+                     "note": "both launches of one frame inside the event pair; the blur is fp64-VALU-bound, see DESIGN.md §4.5"})
+        if not args.no_cpu_baseline:
+            from oracle import oracle as O
+            O.build(ref=False)
+            threads = O.max_threads()
+            osg, odg = O.map_geom(*sgeo), O.map_geom(*dgeo)
+            vx, vy, th = poses[0]
+            t1 = time.perf_counter()
+            w, _ = O.warp(src_h, osg, odg, vx, vy, th, threads=threads)
+            b, _, _ = O.blur(w, odg, np.sin(th), np.cos(th), *sig, threads=threads)
+            o = O.layer_to_occupancy(b.reshape(-1, order="F"), 0.0, 100.0)
+            cpu_s = time.perf_counter() - t1
+            solver.costmap_frame_device(stream, src.data_ptr(), sg, dg, vx, vy, th, *sig, veh.data_ptr(), unc.data_ptr(), occ.data_ptr())
+            torch.cuda.synchronize()
+            out["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "frames/s", "cores": threads, "kind": "port",
+                                   "sample": "one frame, OpenMP over cells (warp, blur), scalar conversion"}
+            out["occupancy_cells_equal_oracle"] = float(np.mean(occ.cpu().numpy() == o))
+        print(json.dumps(out), flush=True)
+    solver.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def bench_plan(args, rank, local_rank, world, dist, dev):
+    """the LocalPlanner pre-step for B candidate ego poses per step (default 1024) on one shared 200-waypoint
+    global path, everything resident in HBM."""
+    import cilqr_amd
+    B, P = args.batch or 1024, 200
+    p = cilqr_amd.default_params()
+    solver = cilqr_amd.Solver(p, max_batch=1, max_horizon=1, max_obstacles=0, device=local_rank)
+    rng = np.random.default_rng(71 + rank)
+    x = 37.25 + np.cumsum(rng.uniform(0.8, 1.2, P))
+    path_h = np.stack([x, 1.2 * np.sin(0.05 * x)], axis=1)
+    k = rng.integers(0, P, B)
+    ego_h = np.stack([x[k] + rng.uniform(-0.4, 0.4, B), path_h[k, 1] + rng.uniform(-1, 1, B), rng.uniform(0, 8, B),
+                      rng.uniform(-1, 1, B)], axis=1)
+    path, ego = torch.from_numpy(path_h).to(dev), torch.from_numpy(ego_h).to(dev)
+    poly = torch.zeros(B, 6, dtype=torch.float64, device=dev)
+    fl = torch.zeros(B, 2, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(k, e0, e1):
+        if e0 is not None:
+            e0.record()
+        solver.local_plan_batch_device(stream, B, P, path.data_ptr(), 0, ego.data_ptr(), poly.data_ptr(), fl.data_ptr())
+        if e1 is not None:
+            e1.record()
+    elapsed, kern_ms = _timed(step, args, dist, dev)
+    if rank == 0:
+        bytes_launch = B * (32 + 64) + 16 * P  # ego in, poly + first/last out, the shared path once
+        achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
+        out = _line("LocalPlanner fits/sec (B candidates, 20x6 column-pivoted QR each)", "fits/s", B * args.steps * world / elapsed,
+                    args, world, elapsed, "f64", "SURVEY 8f-2: %d candidate ego poses per step on one %d-waypoint path" % (B, P),
+                    {"bound": "hbm", "kernel": "local_plan_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch,
+                     "note": "serial-chain bound: one lane per fit, sums kept in the host pre-step's order"})
+        if not args.no_cpu_baseline:
+            from oracle import oracle as O
+            O.build(ref=False)
+            po = O.default_params(50)
+            ns = min(B, 4096)
+            t1 = time.perf_counter()
+            want = np.array([O.local_plan(po, path_h, ego_h[b])[0] for b in range(ns)])
+            cpu_s = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": ns / cpu_s, "unit": "fits/s", "cores": 1, "kind": "port",
+                                   "sample": "the first %d candidates, one thread, ctypes call per fit" % ns}
+            out["coefficients_bit_equal_fraction"] = float(np.mean(np.all(poly.cpu().numpy()[:ns] == want, axis=1)))
+        print(json.dumps(out), flush=True)
+    solver.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=0, help="solves per GPU per step (default: the config's own size)")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "warp", "blur"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "warp", "blur", "occ", "frame", "plan"],
                     help="c2 (default, the config BASELINE.json's metric is quoted on): B=1024 N=50 M=4; c3: B=4096 N=50, 8x32 "
                          "sampled obstacles; c5: B=8192 per GPU N=80 M=16; warp: config 4, 1024x1024 costmap frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -225,6 +427,8 @@ def main():
         return bench_warp(args, rank, local_rank, world, dist, dev)
     if args.workload == "blur":
         return bench_blur(args, rank, local_rank, world, dist, dev)
+    if args.workload in ("occ", "frame", "plan"):
+        return {"occ": bench_occ, "frame": bench_frame, "plan": bench_plan}[args.workload](args, rank, local_rank, world, dist, dev)
     if args.workload == "c2":
         B, N, M = args.batch or 1024, 50, 4
         p = cilqr_amd.default_params(N)
