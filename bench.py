@@ -30,7 +30,10 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (cannot be collected inside this process): FETCH_SIZE
 # doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950, plus WRITE_SIZE.  Keyed by (workload, batch).
-PMC_TRAFFIC_BYTES = {("c2", 1024): 2 * 5645.43e3 + 2560e3}
+PMC_TRAFFIC_BYTES = {("c2", 1024): 2 * 5645.43e3 + 2560e3,
+                     # profiles/r01_wide_rows_summary.md (KB per dispatch): the 1024^2 destination reads a 512^2 patch of the source
+                     ("warp", 1024): 2 * 598.438e3 + 4096e3,
+                     ("occ", 8192): 2 * 131103e3 + 65536e3}
 FP64_VALU_PEAK_TF = 78.6   # vector fp64 = half the 157.3 TF fp32 vector peak of MI355X_MICROARCH.md
 
 
@@ -44,7 +47,16 @@ def bench_warp(args, rank, local_rank, world, dist, dev):
     source/destination resident in HBM, pose stream of scenes.make_c4 (theta 0→2π)."""
     import cilqr_amd
     from cilqr_amd import scenes
-    c4 = scenes.make_c4()
+    S = args.batch or 1024
+    if S == 1024:
+        c4 = scenes.make_c4()
+    else:  # size sweep (not a BASELINE config): same geometry rules, random {0,100} payload with 2 % NaN
+        rng = np.random.default_rng(4 + S)
+        src_s = np.where(rng.random((S, S)) < 0.3, np.float32(100), np.float32(0))
+        src_s[rng.random((S, S)) < 0.02] = np.nan
+        th = np.linspace(0.0, 2 * np.pi, 300, endpoint=False)
+        c4 = dict(src=np.asfortranarray(src_s.astype(np.float32)), src_geom=(S * 0.2, S * 0.2, 0.2, 0.0, 0.0),
+                  dst_geom=(S * 0.1, S * 0.1, 0.1, 0.0, 0.0), poses=np.stack([20.0 * np.cos(th), 20.0 * np.sin(th), th], 1))
     sg, dg = cilqr_amd.map_geom(*c4["src_geom"]), cilqr_amd.map_geom(*c4["dst_geom"])
     solver = cilqr_amd.Solver(cilqr_amd.default_params(), max_batch=1, max_horizon=1, max_obstacles=0, device=local_rank)
     src = torch.from_numpy(np.ascontiguousarray(c4["src"].T)).to(dev)  # column-major payload
@@ -85,14 +97,16 @@ def bench_warp(args, rank, local_rank, world, dist, dev):
         cells = dg.rows * dg.cols
         bytes_launch = 8 * cells  # 4 B read + 4 B write per destination cell
         achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
-        out = {"metric": "costmap warp frames/sec (1024x1024 -> 1024x1024)", "value": args.steps * world / elapsed, "unit": "frames/s",
+        out = {"metric": "costmap warp frames/sec (%dx%d -> %dx%d)" % (sg.rows, sg.cols, dg.rows, dg.cols), "value": args.steps * world / elapsed, "unit": "frames/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 payload / f64 index math",
                "data": "synthetic",
-               "config": {"workload": "BASELINE config 4: 1024x1024 occupancy costmap warp, one frame per step, maps resident in HBM"},
+               "config": {"workload": ("BASELINE config 4: " if S == 1024 else "size sweep: ") +
+                                      "%dx%d occupancy costmap warp, one frame per step, maps resident in HBM" % (S, S)},
                "roofline": {"bound": "hbm", "kernel": "warp_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms,
-                            "algorithmic_bytes_per_launch": bytes_launch}}
+                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC_BYTES.get(("warp", S)),
+                            "traffic_source": "profiles/r01_wide_rows_summary.md (FETCH_SIZE x2 + WRITE_SIZE)" if S == 1024 else None,
+                            "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch}}
         if not args.no_cpu_baseline:
             from oracle import oracle as O
             O.build(ref=False)
@@ -235,7 +249,12 @@ def bench_occ(args, rank, local_rank, world, dist, dev):
     back = torch.zeros(n, dtype=torch.int8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
+    first = []
+
     def step(k, e0, e1):
+        if e0 is not None:
+            first.append((torch.cuda.Event(enable_timing=True), e0))
+            first[-1][0].record()
         solver.occupancy_to_layer_device(stream, occ.data_ptr(), n, layer.data_ptr())
         if e0 is not None:
             e0.record()
@@ -250,7 +269,12 @@ def bench_occ(args, rank, local_rank, world, dist, dev):
                     n * args.steps * world / elapsed, args, world, elapsed, "i8 / f32",
                     "SURVEY 8f-4: fromOccupancyGrid + toOccupancyGrid(-1, 100) round trip, %d cells, buffers resident in HBM" % n,
                     {"bound": "hbm", "kernel": "layer_to_occ_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch})
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC_BYTES.get(("occ", S)),
+                     "traffic_source": "profiles/r01_wide_rows_summary.md (FETCH_SIZE x2 + WRITE_SIZE)" if S == 8192 else None,
+                     "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch})
+        to_layer_ms = float(np.mean([a.elapsed_time(b) for a, b in first]))
+        out["occ_to_layer_kernel"] = {"kernel_ms": to_layer_ms, "achieved": bytes_launch / (to_layer_ms * 1e-3) / 1e9, "unit": "GB/s",
+                                      "frac": bytes_launch / (to_layer_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         out["round_trip_exact"] = bool(torch.equal(back, occ))
         if not args.no_cpu_baseline:
             from oracle import oracle as O

@@ -562,3 +562,46 @@ def test_costmap_frame_equals_its_three_steps(cilqr, oracle, solver):
     same = np.ones(nd, dtype=bool)
     same[fin] = ulp == 0
     assert np.array_equal(occ[::-1][same], oracle.layer_to_occupancy(w_unc, 0.0, 100.0)[::-1][same])
+
+
+def test_error_behaviour_with_a_live_handle(cilqr):
+    """The reference solver never throws (I/iLQR.cpp:240-242 just prints); the C-ABI turns misuse into return codes:
+    sizes above what cilqr_create reserved, missing obstacle tables, null required pointers — and an empty batch is OK."""
+    from cilqr_amd import scenes
+    p = cilqr.default_params(50)
+    s = cilqr.Solver(p, max_batch=8, max_horizon=50, max_obstacles=2, device=0)
+    try:
+        sc = scenes.make_static(8, 50, 2, p, 5)
+        ok = s.solve_batch(50, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"])
+        assert ok["iters"].min() >= 1
+        big = scenes.make_static(9, 50, 2, p, 5)
+        with pytest.raises(cilqr.CilqrError, match="-1"):  # CILQR_ERR_ARG: B > max_batch
+            s.solve_batch(50, big["x0"], big["U"], big["poly"], big["xplan_fl"], big["obs_pose"], big["obs_dim"])
+        m3 = scenes.make_static(8, 50, 3, p, 5)
+        with pytest.raises(cilqr.CilqrError, match="-1"):  # M > max_obstacles
+            s.solve_batch(50, m3["x0"], m3["U"], m3["poly"], m3["xplan_fl"], m3["obs_pose"], m3["obs_dim"])
+        n60 = scenes.make_static(8, 60, 2, cilqr.default_params(60), 5)
+        with pytest.raises(cilqr.CilqrError, match="-1"):  # N > max_horizon
+            s.solve_batch(60, n60["x0"], n60["U"], n60["poly"], n60["xplan_fl"], n60["obs_pose"], n60["obs_dim"])
+        L = cilqr.lib()
+        import ctypes as C
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+        X = np.zeros((8, 4 * 51))
+        U = sc["U"].copy()
+        # M > 0 with null obstacle tables; null X_out
+        assert L.cilqr_solve_batch(s._h, 8, 50, 2, dp(sc["x0"]), dp(U), dp(sc["poly"]), dp(sc["xplan_fl"]), None, None, None,
+                                   dp(X), None, None, None, C.c_uint32(0)) == -1
+        assert b"obstacle" in L.cilqr_last_error()
+        assert L.cilqr_solve_batch(s._h, 8, 50, 0, dp(sc["x0"]), dp(U), dp(sc["poly"]), dp(sc["xplan_fl"]), None, None, None,
+                                   None, None, None, None, C.c_uint32(0)) == -1
+        # empty batch: nothing to do, not an error
+        assert L.cilqr_solve_batch(s._h, 0, 50, 0, None, None, None, None, None, None, None, None, None, None, None, C.c_uint32(0)) == 0
+        # the handle still works after the refusals
+        again = s.solve_batch(50, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"])
+        assert np.array_equal(again["U"], ok["U"])
+    finally:
+        s.close()
+    q = cilqr.default_params(50)
+    q.num_states = 5  # BASELINE.json says nx=5; the reference is nx=4 and the library refuses to guess
+    with pytest.raises(cilqr.CilqrError, match="-4"):
+        cilqr.Solver(q, max_batch=1, max_horizon=50, max_obstacles=0, device=0)

@@ -22,6 +22,17 @@ constexpr int TILE_I = 64;
 constexpr int TILE_J = 16;
 constexpr int NTHREADS = 256;  // 4 wavefronts: wave w handles j = w, w+4, w+8, w+12 of the tile
 
+// -(t / res) as far as its truncation to an index is concerned.  t·(1/res) differs from the correctly rounded quotient by
+// at most a few ulp, so the two truncate alike unless an integer lies within that distance; only then (cell centres that
+// map onto a source-cell boundary to within 1e-13 cells) is the IEEE division the reference performs carried out.
+__device__ __forceinline__ double neg_quotient_for_trunc(double t, double res, double rres) {
+#pragma clang fp contract(off)
+  const double q = -(t * rres);
+  const double k = __builtin_rint(q);
+  if (__builtin_fabs(q - k) > __builtin_fabs(q) * 0x1p-48 + 0x1p-1000) return q;
+  return -(t / res);
+}
+
 __global__ __launch_bounds__(NTHREADS) void warp_kernel(WarpArgs a, int tiles_i, int n_tiles) {
 #pragma clang fp contract(off)
   // XCD-aware remap: workgroup ids are dealt round-robin over the 8 XCDs (speed only, never correctness).
@@ -40,6 +51,7 @@ __global__ __launch_bounds__(NTHREADS) void warp_kernel(WarpArgs a, int tiles_i,
   const double Cx = (a.dg.pos_x + off_dx) + a.dg.res * (double)(-i);
   const double off_sx = 0.5 * a.sg.len_x, off_sy = 0.5 * a.sg.len_y;
   const double cxc = Cx * a.cos_t, cxs = Cx * a.sin_t;
+  const double rres = 1.0 / a.sg.res;
   unsigned long long oob = 0;
 #pragma unroll
   for (int jj = 0; jj < TILE_J / 4; ++jj) {
@@ -49,8 +61,8 @@ __global__ __launch_bounds__(NTHREADS) void warp_kernel(WarpArgs a, int tiles_i,
     const double x_og = (cxc - Cy * a.sin_t) + a.vx;
     const double y_og = (cxs + Cy * a.cos_t) + a.vy;
     // getIndexFromPosition / checkIfPositionWithinMap
-    const double nx = -(((x_og - off_sx) - a.sg.pos_x) / a.sg.res);
-    const double ny = -(((y_og - off_sy) - a.sg.pos_y) / a.sg.res);
+    const double nx = neg_quotient_for_trunc((x_og - off_sx) - a.sg.pos_x, a.sg.res, rres);
+    const double ny = neg_quotient_for_trunc((y_og - off_sy) - a.sg.pos_y, a.sg.res, rres);
     const double tx = -1.0 * ((x_og - a.sg.pos_x) - off_sx);
     const double ty = -1.0 * ((y_og - a.sg.pos_y) - off_sy);
     const bool fin = (nx > -2e9 && nx < 2e9 && ny > -2e9 && ny < 2e9);
