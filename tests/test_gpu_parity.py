@@ -605,3 +605,60 @@ def test_error_behaviour_with_a_live_handle(cilqr):
     q.num_states = 5  # BASELINE.json says nx=5; the reference is nx=4 and the library refuses to guess
     with pytest.raises(cilqr.CilqrError, match="-4"):
         cilqr.Solver(q, max_batch=1, max_horizon=50, max_obstacles=0, device=0)
+
+
+def test_replay_tool_closed_loop_against_oracle(cilqr, oracle, tmp_path):
+    """bin/cilqr_replay (host/replay_main.cpp): six recorded ticks — ego advancing along the previous plan, an obstacle
+    appearing at tick 2 and gone at tick 5, the warm start carried un-shifted from tick to tick (I/iLQR.cpp:253) — replayed
+    through the adapter and compared, tick by tick, with the oracle driven the same way.  Output is the
+    vehiclepub/Experiment flattening (I/ilqr_uncertainty_node.cpp:243-284)."""
+    import os
+    import subprocess
+    from conftest import PKG
+    exe = os.path.join(PKG, "bin", "cilqr_replay")
+    assert os.path.exists(exe), "bin/cilqr_replay not built (make -C %s)" % PKG
+    N, P = 50, 200
+    po = oracle.default_params(N)
+    i = np.arange(float(P))
+    path = np.stack([i, 0.5 * np.sin(0.05 * i)], axis=1)
+    ego = np.array([0.0, 0.1, 3.0, 0.02])
+    U = oracle.default_control_seq(N) if hasattr(oracle, "default_control_seq") else None
+    if U is None:
+        U = cilqr.default_control_seq(N)
+    obst = {2: [(22.0, 0.9, 0.0, 0.1, 4.79, 2.16)], 3: [(22.0, 0.9, 0.0, 0.1, 4.79, 2.16), (40.0, -1.2, 0.0, -0.05, 4.2, 1.9)],
+            4: [(40.0, -1.2, 0.0, -0.05, 4.2, 1.9)]}
+    lines = ["# six ticks, closed loop on the oracle's own plan", "cilqr-replay 1", "horizon %d" % N, "path %d" % P]
+    lines += ["%r %r" % (float(a), float(b)) for a, b in path]
+    want = []
+    for tick in range(6):
+        obs = obst.get(tick, [])
+        lines += ["tick", "ego " + " ".join(repr(float(v)) for v in ego), "obstacles %d" % len(obs)]
+        lines += [" ".join(repr(float(v)) for v in o) for o in obs]
+        coeffs, ref = oracle.local_plan(po, path, ego)
+        M = len(obs)
+        pose = np.array([[list(o[:4]) * 1 for _ in range(N)] for o in obs]).reshape(M, N, 4) if M else None
+        dim = np.array([[list(o[4:]) for _ in range(N)] for o in obs]).reshape(M, N, 2) if M else None
+        r = oracle.solve(po, N, ego, U, coeffs, ref[0, 0], ref[-1, 0], None if not M else pose.reshape(M, 4 * N),
+                         None if not M else dim.reshape(M, 2 * N))
+        want.append((ego.copy(), r))
+        U = r["U"]
+        ego = r["X"].reshape(N + 1, 4)[1].copy()
+    log = tmp_path / "ticks.log"
+    log.write_text("\n".join(lines) + "\n")
+    out = subprocess.run([exe, str(log)], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    assert len(out) == 6
+    for line, (e, r) in zip(out, want):
+        w = line.split()
+        assert w[0] == "experiment" and w[9] == "X" and w[10 + 4 * (N + 1)] == "U"
+        assert np.array_equal(np.array(w[1:5], dtype=float), e)  # start_pos
+        assert float(w[5]) > 0.0  # planning_time
+        assert int(w[6]) == r["iters"] and int(w[7]) == r["status"]
+        X = np.array(w[10:10 + 4 * (N + 1)], dtype=float)
+        Uo = np.array(w[11 + 4 * (N + 1):], dtype=float)
+        assert Uo.size == 2 * N
+        assert np.max(np.abs(Uo - r["U"])) < TIGHT and np.max(np.abs(X - r["X"])) < 1e-7
+    # malformed input is an error with a message, not a crash
+    bad = tmp_path / "bad.log"
+    bad.write_text("cilqr-replay 1\nhorizon 50\npath 2\n0 0\n")
+    p = subprocess.run([exe, str(bad)], capture_output=True, text=True)
+    assert p.returncode == 1 and "replay log" in p.stderr

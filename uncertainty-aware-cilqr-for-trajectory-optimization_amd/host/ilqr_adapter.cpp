@@ -98,6 +98,19 @@ void iLQR::run_step(const double ego_state[4]) {
   get_optimal_control_seq(ego_state, control_seq_, coeffs, x_local_plan);  // I/iLQR.cpp:253: warm start persists
 }
 
+Experiment flatten_experiment(const double start_pos[4], double planning_time, const Matrix& X, const Matrix& U) {
+  Experiment e;
+  e.planning_time = planning_time;
+  e.start_pos.assign(start_pos, start_pos + 4);
+  e.X.resize(4 * (size_t)(U.cols + 1));
+  e.U.resize(2 * (size_t)U.cols);
+  for (int i = 0; i < U.cols + 1; ++i)
+    for (int r = 0; r < 4; ++r) e.X[4 * i + r] = X(r, i);
+  for (int i = 0; i < U.cols; ++i)
+    for (int r = 0; r < 2; ++r) e.U[2 * i + r] = U(r, i);
+  return e;
+}
+
 int iLQR::run_candidates(const std::vector<double>& ego_states) {
   const int B = (int)(ego_states.size() / 4), N = params.horizon, M = (int)obstacles_.size();
   if (B < 1 || B > max_candidates_) throw std::runtime_error("run_candidates: candidate count outside [1, max_candidates]");

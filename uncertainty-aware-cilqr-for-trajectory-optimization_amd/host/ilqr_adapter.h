@@ -45,6 +45,15 @@ class Obstacle {
   Matrix relative_pos_array;  // 4 × horizon: (x, y, v, theta) per step
 };
 
+// vehiclepub/Experiment as the node fills it (I/ilqr_uncertainty_node.cpp:243-284): start_pos[4], X flattened column by
+// column (4 per step, horizon + 1 steps), U likewise (2 per step), planning_time in seconds.  (Its ros::Time start_time
+// belongs to the caller.)  Column-major flattening is the memory order of X_result / U_result, so these are copies.
+struct Experiment {
+  double planning_time = 0.0;
+  std::vector<double> start_pos, X, U;
+};
+Experiment flatten_experiment(const double start_pos[4], double planning_time, const Matrix& X, const Matrix& U);
+
 class iLQR {
  public:
   // max_candidates > 1 reserves device buffers for run_candidates().
