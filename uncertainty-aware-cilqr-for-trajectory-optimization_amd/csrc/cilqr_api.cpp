@@ -278,7 +278,6 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
     G = 32;
     while (G > 1 && (long)G * B > 65536) G >>= 1;
   }
-  if (h->diag) G = 64;  // phase stamps exist in the wavefront-per-solve family only
   if (G == 64) HIP_TRY(cilqr::launch_solve_wave(a, (hipStream_t)stream));
   else HIP_TRY(cilqr::launch_solve_groups(a, G, h->d_ws, (hipStream_t)stream));
   return CILQR_OK;

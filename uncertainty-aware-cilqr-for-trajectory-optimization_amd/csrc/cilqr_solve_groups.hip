@@ -82,13 +82,30 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
     UF(L.ua(), t, 1) = Ug[2 * t + 1];
   }
   const double* wts = a.obs_weight ? a.obs_weight + (size_t)b * M : nullptr;
-  for (int m = 0; m < M; ++m)  // obstacle table, I/Obstacle.cpp:41-62
+  // Obstacle table, I/Obstacle.cpp:41-62.  An obstacle whose pose and dimensions are the same in every column (how the
+  // reference node feeds static obstacles: one pose replicated over the horizon, I/ilqr_uncertainty_node.cpp:175-185) gets a
+  // bit in `held`: phase L then reads its step-0 row for every step — the same values, but one cache-resident line per
+  // field instead of a stream of N·6 doubles per obstacle, solve and iteration from HBM.
+  unsigned long long held = 0;
+  for (int m = 0; m < M; ++m) {
+    const double* pose0 = a.obs_pose + ((size_t)b * M + m) * N * 4;
+    const double* dim0 = a.obs_dim + ((size_t)b * M + m) * N * 2;
+    bool same = true;
     for (int t = g; t < N; t += G) {
-      const ObsEntry e = make_obs_entry(kp, a.obs_pose + (((size_t)b * M + m) * N + t) * 4, a.obs_dim + (((size_t)b * M + m) * N + t) * 2);
+      const double* pose = pose0 + (size_t)t * 4;
+      const double* dim = dim0 + (size_t)t * 2;
+      same = same && pose[0] == pose0[0] && pose[1] == pose0[1] && pose[2] == pose0[2] && pose[3] == pose0[3] &&
+             dim[0] == dim0[0] && dim[1] == dim0[1];
+      const ObsEntry e = make_obs_entry(kp, pose, dim);
       double* o = tab + (size_t)(m * TABF * N + t) * S;
       const size_t fs = (size_t)N * S;  // field stride
       o[0] = e.ox; o[fs] = e.oy; o[2 * fs] = e.co; o[3 * fs] = e.so; o[4 * fs] = e.ia2; o[5 * fs] = e.ib2;
     }
+    int all = same ? 1 : 0;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) all &= __shfl_xor(all, o, WAVE);
+    if (all && m < 64) held |= 1ull << m;
+  }
   mem_sync();
 
   auto store_state = [&](int base, int t, const State& s) {
@@ -134,19 +151,21 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
   const int max_it = kp.max_iterations;
   const double dt = kp.dt, two_wvel = kp.w_vel * 2;
 
+  unsigned long long tL = 0, tR = 0, tF = 0, nL = 0, nR = 0;
+  const unsigned long long t_begin = __builtin_readcyclecounter();
   for (int it = 0; it < max_it && !handover; ++it) {
     ++iters;
     // ---- phase L: this group's N steps over its G lanes
+    unsigned long long t0 = a.diag ? __builtin_readcyclecounter() : 0;
     double Jpart = 0.0;
     for (int t = g; t < N; t += G) {
       const double px = XF(xc, t, 0), py = XF(xc, t, 1);
       const int cs = closest_sample(NS, grid, px, py, sample_at);
       double cx, cy;
       sample_xy(grid, pc, cs, cx, cy);
-      const double* tt = tab + (size_t)t * S;
       const size_t fs = (size_t)N * S;
       auto obs = [&](int m, ObsEntry& e, double& w) {
-        const double* p = tt + (size_t)m * TABF * fs;
+        const double* p = tab + (size_t)(((m < 64 && ((held >> m) & 1)) ? 0 : t)) * S + (size_t)m * TABF * fs;
         e.ox = p[0]; e.oy = p[fs]; e.co = p[2 * fs]; e.so = p[3 * fs]; e.ia2 = p[4 * fs]; e.ib2 = p[5 * fs];
         w = wts ? wts[m] : kp.w_obstacle;
       };
@@ -160,6 +179,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
     J_new = group_sum<G>(Jpart);
     j_valid = true;
     mem_sync();
+    if (a.diag) { const unsigned long long t1 = __builtin_readcyclecounter(); tL += t1 - t0; ++nL; t0 = t1; }
 
     const bool accept = J_new < J_old;
     if (!accept && !faithful) {
@@ -210,6 +230,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
       break;
     }
     mem_sync();
+    if (a.diag) { const unsigned long long t1 = __builtin_readcyclecounter(); tR += t1 - t0; ++nR; t0 = t1; }
 
     // ---- phase F: forward pass
     {
@@ -257,10 +278,11 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
       }
     }
     mem_sync();
+    if (a.diag) tF += __builtin_readcyclecounter() - t0;
 
     if (accept) {
-      int t0 = xc; xc = xn; xn = t0;
-      int t1 = uc; uc = un; un = t1;
+      int sx = xc; xc = xn; xn = sx;
+      int su = uc; uc = un; un = su;
       j_valid = false;
       lamb = lamb / kp.lamb_factor;
       if (fabs(J_new - J_old) < kp.tolerance) { status = CILQR_EXIT_TOLERANCE; break; }
@@ -299,6 +321,10 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
       J_new = group_sum<G>(Jpart);
     }
     if (g == 0) a.J_out[b] = J_new;
+  }
+  if (a.diag && g == 0) {  // {prologue, L, R, F, epilogue, #L, #R, total}: prologue/epilogue not separated here
+    unsigned long long* d = a.diag + (size_t)b * 8;
+    d[0] = 0; d[1] = tL; d[2] = tR; d[3] = tF; d[4] = 0; d[5] = nL; d[6] = nR; d[7] = __builtin_readcyclecounter() - t_begin;
   }
   if (g == 0) {
     if (a.iters_out) a.iters_out[b] = iters;
