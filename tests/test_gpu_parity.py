@@ -662,3 +662,43 @@ def test_replay_tool_closed_loop_against_oracle(cilqr, oracle, tmp_path):
     bad.write_text("cilqr-replay 1\nhorizon 50\npath 2\n0 0\n")
     p = subprocess.run([exe, str(bad)], capture_output=True, text=True)
     assert p.returncode == 1 and "replay log" in p.stderr
+
+
+def test_config5_shard_full_size_properties(cilqr, oracle):
+    """BASELINE config 5 at its per-GPU size (B = 8192, N = 80, M = 16; grouped family, G = 8), through properties that do
+    not need 8192 oracle solves: (a) a 192-solve sample against the oracle; (b) solves are independent — a permuted batch
+    gives the permuted outputs bit for bit, although every solve then sits in a different wavefront and lane group;
+    (c) idempotence — the same call twice gives identical bits; (d) the held-row path (obstacles constant over the
+    horizon are read from one table row) next to the streamed path: moving one obstacle by 1 cm in the last step of 64
+    solves makes it time-varying there — those solves follow the oracle on the changed scene, all others keep their bits."""
+    from cilqr_amd import scenes
+    p = cilqr.default_params(80)
+    sc = scenes.make_c5(8192, p)
+    B, N, M = 8192, 80, 16
+    s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M, device=0)
+    try:
+        got = _gpu_batch(s, sc)
+        again = _gpu_batch(s, sc)
+        perm = np.random.default_rng(3).permutation(B)
+        scp = dict(sc)
+        for k in ("x0", "U", "poly", "xplan_fl", "obs_pose", "obs_dim"):
+            scp[k] = np.ascontiguousarray(sc[k][perm])
+        gotp = _gpu_batch(s, scp)
+        # time-varying twin: step N-1 of obstacle 3 moved by 1 cm in the first 64 solves
+        sct = dict(sc)
+        pose = sc["obs_pose"].copy().reshape(B, M, N, 4)
+        pose[:64, 3, N - 1, 0] += 0.01
+        sct["obs_pose"] = pose.reshape(B, M, 4 * N)
+        gott = _gpu_batch(s, sct)
+    finally:
+        s.close()
+    for k in ("U", "X", "J", "iters", "status"):
+        assert np.array_equal(got[k], again[k]), k
+        assert np.array_equal(got[k][perm], gotp[k]), k
+        assert np.array_equal(got[k][64:], gott[k][64:]), k  # untouched solves: unchanged
+    idx = np.concatenate([np.arange(64), np.arange(4000, 4064), np.arange(B - 64, B)])
+    sub = {k: (v[idx] if isinstance(v, np.ndarray) else v) for k, v in sc.items()}
+    _compare({k: v[idx] for k, v in got.items()}, _oracle_batch(oracle, N, sub), TIGHT, "c5 sample")
+    subt = {k: (v[:64] if isinstance(v, np.ndarray) else v) for k, v in sct.items()}
+    _compare({k: v[:64] for k, v in gott.items()}, _oracle_batch(oracle, N, subt), TIGHT, "c5 streamed obstacle")
+    assert np.isfinite(got["U"]).all() and (got["iters"] >= 1).all()
