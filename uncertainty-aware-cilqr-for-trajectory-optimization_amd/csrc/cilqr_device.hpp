@@ -299,39 +299,49 @@ __device__ __forceinline__ double lin_step(const KParams& kp, double px, double 
   // --- obstacles (I/Constraints.cpp:177-187, I/Obstacle.cpp:39-112)
   const double fxp = px + ct * kp.ego_front, fyp = py + st * kp.ego_front;
   const double rxp = px - ct * kp.ego_rear, ryp = py - st * kp.ego_rear;
-  ObsEntry e_next;
-  double w_next = 0.0;
-  if (M > 0) obs(0, e_next, w_next);
-  for (int m = 0; m < M; ++m) {
-    const ObsEntry e = e_next;
-    const double w = w_next;
-    if (m + 1 < M) obs(m + 1, e_next, w_next);  // the next entry's loads fly while this one computes
+  // One obstacle entry into the gradient / Hessian sums.  The reference's factor -2 of c-dot (I/Obstacle.cpp:75-78) is
+  // carried in the scalar factors (exact: powers of two), not applied to the vector.
+  const double svf = -2 * (kp.q2_front * kp.q1_front), smf = 4 * (kp.q2_front * kp.q2_front * kp.q1_front);
+  const double svr = -2 * (kp.q2_rear * kp.q1_rear), smr = 4 * (kp.q2_rear * kp.q2_rear * kp.q1_rear);
+  auto add_entry = [&](const ObsEntry& e, double w) {
     double gx = 0.0, gy = 0.0, gxx = 0.0, gxy = 0.0, gyy = 0.0;
 #pragma unroll
     for (int side = 0; side < 2; ++side) {
       const double ex = (side == 0 ? fxp : rxp) - e.ox, ey = (side == 0 ? fyp : ryp) - e.oy;
-      const double q1 = side == 0 ? kp.q1_front : kp.q1_rear, q2 = side == 0 ? kp.q2_front : kp.q2_rear;
+      const double q2 = side == 0 ? kp.q2_front : kp.q2_rear;
       const double d0 = e.co * ex + e.so * ey;
       const double d1 = e.co * ey - e.so * ex;
       const double g0 = d0 * e.ia2, g1 = d1 * e.ib2;
       const double c = 1 - (g0 * d0 + g1 * d1);
-      const double cd0 = -2 * (e.co * g0 - e.so * g1);
-      const double cd1 = -2 * (e.so * g0 + e.co * g1);
+      const double h0 = e.co * g0 - e.so * g1;  // c-dot = -2 (h0, h1)
+      const double h1 = e.so * g0 + e.co * g1;
       const double ee = exp_fast(q2 * c);
-      const double sv = q2 * q1 * ee;
-      const double sm = q2 * q2 * q1 * ee;
-      gx += sv * cd0;
-      gy += sv * cd1;
-      gxx += (sm * cd0) * cd0;
-      gxy += (sm * cd0) * cd1;
-      gyy += (sm * cd1) * cd1;
+      const double sv = (side == 0 ? svf : svr) * ee;
+      const double sm = (side == 0 ? smf : smr) * ee;
+      gx += sv * h0;
+      gy += sv * h1;
+      gxx += (sm * h0) * h0;
+      gxy += (sm * h0) * h1;
+      gyy += (sm * h1) * h1;
     }
     lx0 += gx * w;
     lx1 += gy * w;
     h00 += gxx * w;
     h01 += gxy * w;
     h11 += gyy * w;
+  };
+  // two entries in flight, alternating registers: the next entry's loads fly while this one computes
+  ObsEntry ea, eb;
+  double wa = 0.0, wb = 0.0;
+  if (M > 0) obs(0, ea, wa);
+  int m = 0;
+  for (; m + 1 < M; m += 2) {
+    obs(m + 1, eb, wb);
+    add_entry(ea, wa);
+    if (m + 2 < M) obs(m + 2, ea, wa);
+    add_entry(eb, wb);
   }
+  if (m < M) add_entry(ea, wa);
 
   // --- control cost (I/Constraints.cpp:110-131)
   const double e1 = exp_fast(kp.q2_acc * (u0 - kp.acc_max));

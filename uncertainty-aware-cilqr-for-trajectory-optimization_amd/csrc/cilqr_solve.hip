@@ -15,7 +15,7 @@
 //   U a/b [N][2]        controls, double-buffered (U / U_new)
 //   rec   [N][16]       per-step linearisation {l_x(3), l_xx(3), l_u(2), l_uu(2), A/B entries(6)}
 //   kK    [N][10]       feed-forward k and feedback K of the backward pass
-//   tab   [M][6][N]     obstacle table (when it fits; else the same layout in a global workspace)
+//   tab   [M][N][6]     obstacle table (when it fits; else the same layout in a global workspace)
 // Phases per iteration:
 //   L  lanes = timesteps: closest path sample, tracking + obstacle + control barrier derivatives, A/B entries,
 //      the stage cost of get_J, wavefront-shuffle reduction of J;
@@ -53,14 +53,17 @@ struct LdsSamples {  // sample accessor over the LDS copy
   __device__ __forceinline__ void operator()(int s, double& x, double& y) const { x = samp[2 * s]; y = samp[2 * s + 1]; }
 };
 
-struct TabObstacles {  // obstacle accessor over the [m][field][t] table (LDS or global)
-  const double* tab;   // already offset by t
+struct TabObstacles {  // obstacle accessor over the [m][t][field] table (LDS or global)
+  const double* tab;   // already offset by t: entry of obstacle 0 at this lane's step
   const double* wts;
   int N;
   double w_default;
+  // An entry is 48 contiguous bytes, read as three 16-byte accesses.  In LDS the lane stride of 12 dwords makes each
+  // quarter-wave's b128 reads cover all 64 banks exactly once (12·i mod 64, i < 16, are 16 distinct multiples of 4).
   __device__ __forceinline__ void operator()(int m, ObsEntry& e, double& w) const {
-    const double* p = tab + (size_t)m * TABF * N;
-    e.ox = p[0]; e.oy = p[N]; e.co = p[2 * N]; e.so = p[3 * N]; e.ia2 = p[4 * N]; e.ib2 = p[5 * N];
+    const double2* p = reinterpret_cast<const double2*>(tab + (size_t)m * TABF * N);
+    const double2 a = p[0], b = p[1], c = p[2];
+    e.ox = a.x; e.oy = a.y; e.co = b.x; e.so = b.y; e.ia2 = c.x; e.ib2 = c.y;
     w = wts ? wts[m] : w_default;
   }
 };
@@ -77,7 +80,7 @@ __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int
     const int cs = closest_sample(S, grid, px, py, LdsSamples{samp});
     Rec c;
     Jpart += lin_step(kp, px, py, xr[2], xr[4], xr[5], U[2 * t], U[2 * t + 1], xn[2], xn[4], xn[5], samp[2 * cs],
-                      samp[2 * cs + 1], M, TabObstacles{tab + t, wts, N, kp.w_obstacle}, c);
+                      samp[2 * cs + 1], M, TabObstacles{tab + (size_t)t * TABF, wts, N, kp.w_obstacle}, c);
     double* r = rec + t * REC;
     r[0] = c.lx0; r[1] = c.lx1; r[2] = c.lx2; r[3] = c.l00; r[4] = c.l01; r[5] = c.l11;
     r[6] = c.lu0; r[7] = c.lu1; r[8] = c.luu0; r[9] = c.luu1;
@@ -277,8 +280,8 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   for (int m = 0; m < M; ++m) {  // obstacle table, I/Obstacle.cpp:41-62
     for (int t = lane; t < N; t += WAVE) {
       const ObsEntry e = make_obs_entry(kp, a.obs_pose + (((size_t)b * M + m) * N + t) * 4, a.obs_dim + (((size_t)b * M + m) * N + t) * 2);
-      double* o = tab + (size_t)m * TABF * N + t;
-      o[0] = e.ox; o[N] = e.oy; o[2 * N] = e.co; o[3 * N] = e.so; o[4 * N] = e.ia2; o[5 * N] = e.ib2;
+      double* o = tab + ((size_t)m * N + t) * TABF;
+      o[0] = e.ox; o[1] = e.oy; o[2] = e.co; o[3] = e.so; o[4] = e.ia2; o[5] = e.ib2;
     }
   }
   __syncthreads();
