@@ -425,6 +425,9 @@ def main():
                     help="c2 (default, the config BASELINE.json's metric is quoted on): B=1024 N=50 M=4; c3: B=4096 N=50, 8x32 "
                          "sampled obstacles; c5: B=8192 per GPU N=80 M=16; warp: config 4, 1024x1024 costmap frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--materialised", action="store_true",
+                    help="c3 only: pass the 256 sampled obstacles as 256 ordinary obstacle tables (cilqr_solve_batch_device) instead "
+                         "of the compact nominal + offsets form (cilqr_solve_batch_sampled_device)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -468,14 +471,21 @@ def main():
         p = cilqr_amd.default_params(N)
         sc = scenes.make_c3(B, p)
         M = sc["M"]
-        wl = "BASELINE config 3: B=%d CILQR solves per GPU per step, N=50, 8 moving obstacles x 32 Gaussian samples (M=256, weight 1/32)" % B
+        wl = ("BASELINE config 3: B=%d CILQR solves per GPU per step, N=50, 8 moving obstacles x 32 Gaussian samples (M=256, weight 1/32), "
+              % B) + ("materialised obstacle tables" if args.materialised else "compact form (nominal trajectories + sample offsets)")
     solver = cilqr_amd.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M, device=local_rank)
 
     def dv(a, dtype=torch.float64):
         return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).to(dev)
     x0, U0, poly, xpl = dv(sc["x0"]), dv(sc["U"]), dv(sc["poly"]), dv(sc["xplan_fl"])
-    pose, dim = dv(sc["obs_pose"]), dv(sc["obs_dim"])
-    wts = dv(sc["obs_weight"]) if sc["obs_weight"] is not None else None
+    sampled = args.workload == "c3" and not args.materialised
+    if sampled:  # compact form: nominal trajectories + per-sample offsets (cilqr_solve_batch_sampled_device)
+        pose, dim, offs = dv(sc["nom_pose"]), dv(sc["nom_dim"]), dv(sc["offsets"])
+        n_dyn, n_smp = sc["offsets"].shape[1], sc["offsets"].shape[2]
+        wts = None
+    else:
+        pose, dim = dv(sc["obs_pose"]), dv(sc["obs_dim"])
+        wts = dv(sc["obs_weight"]) if sc["obs_weight"] is not None else None
     U = U0.clone()
     X = torch.zeros(B, 4 * (N + 1), dtype=torch.float64, device=dev)
     J = torch.zeros(B, dtype=torch.float64, device=dev)
@@ -490,9 +500,14 @@ def main():
         U.copy_(U0)
         if k is not None:
             ev0[k].record()
-        solver.solve_batch_device(stream, B, N, M, x0.data_ptr(), U.data_ptr(), poly.data_ptr(), xpl.data_ptr(), pose.data_ptr(),
-                                  dim.data_ptr(), wts.data_ptr() if wts is not None else 0, X.data_ptr(), J.data_ptr(),
-                                  iters.data_ptr(), status.data_ptr())
+        if sampled:
+            solver.solve_batch_sampled_device(stream, B, N, n_dyn, n_smp, x0.data_ptr(), U.data_ptr(), poly.data_ptr(), xpl.data_ptr(),
+                                              pose.data_ptr(), dim.data_ptr(), offs.data_ptr(), sc["sample_weight"], X.data_ptr(),
+                                              J.data_ptr(), iters.data_ptr(), status.data_ptr())
+        else:
+            solver.solve_batch_device(stream, B, N, M, x0.data_ptr(), U.data_ptr(), poly.data_ptr(), xpl.data_ptr(), pose.data_ptr(),
+                                      dim.data_ptr(), wts.data_ptr() if wts is not None else 0, X.data_ptr(), J.data_ptr(),
+                                      iters.data_ptr(), status.data_ptr())
         if k is not None:
             ev1[k].record()
         solver.argmin_device(stream, B, J.data_ptr(), pair.data_ptr())
@@ -526,6 +541,8 @@ def main():
     out = None
     if rank == 0:
         bytes_launch = algorithmic_bytes_per_solve(N, M) * B
+        if sampled:  # SURVEY §8(d) compact form: nominal 6·n_dyn·N + 3 offsets per sample instead of 6·M·N
+            bytes_launch = (8 * (4 + 2 * N + 6 + 2 + 6 * n_dyn * N + 3 * n_dyn * n_smp) + 8 * (2 * N + 4 * (N + 1) + 1) + 8) * B
         achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
         # fp64 VALU work actually needed per solve: accepted iterations k = (iters - 5)/2 for λ-exits
         flops_solve = mean_iters * N * (6 * 200 + 100 * M + 800)
@@ -551,7 +568,11 @@ def main():
         hb = None
         for _ in range(reps + 1):  # first call untimed
             th = time.perf_counter()
-            solver.solve_batch(N, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"], sc["obs_weight"])
+            if sampled:
+                solver.solve_batch_sampled(N, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["nom_pose"], sc["nom_dim"], sc["offsets"],
+                                           sc["sample_weight"])
+            else:
+                solver.solve_batch(N, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"], sc["obs_weight"])
             th = time.perf_counter() - th
             hb = th if hb is None else min(hb, th)
         out["host_buffer_api"] = {"value": B / hb, "unit": "solves/s", "ms_per_batch": 1e3 * hb,

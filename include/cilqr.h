@@ -195,6 +195,27 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
                              double* X_out, double* J_out, int32_t* iters_out, int32_t* status_out,
                              uint32_t flags);
 
+/* Sampled obstacles (the "uncertainty-aware" batch of BASELINE config 3: n_obs moving obstacles × n_samples Gaussian pose
+ * samples, every sample an Obstacle of its own with Parameters::w_obstacle = 1/n_samples, I/Constraints.cpp:177-187).
+ * Exactly cilqr_solve_batch(_device) with M = n_obs·n_samples obstacles where obstacle m = o·n_samples + s has
+ *   pose[t] = (x_o[t] + dx, y_o[t] + dy, v_o[t], theta_o[t] + dtheta),  dim[t] = dim_o[t],  weight = sample_weight,
+ * (dx, dy, dtheta) = sample_offset[b][o][s], but taking the compact form: the materialised tables are n_samples times
+ * larger and, not fitting on chip, would be streamed from HBM once per iteration.
+ *   nom_pose [B][n_obs][4*N], nom_dim [B][n_obs][2*N], sample_offset [B][n_obs][n_samples][3]
+ * n_obs·n_samples counts against max_obstacles of cilqr_create; n_samples ≥ 2.  Sample headings come from the angle-addition
+ * formulas and the ellipse semi-axes from reciprocals refined to ≈1 ulp: results agree with the materialised call to ≈1e-12,
+ * not bit for bit. */
+int cilqr_solve_batch_sampled(cilqr_handle* h, int B, int N, int n_obs, int n_samples,
+                              const double* x0, double* U, const double* poly, const double* xplan_fl,
+                              const double* nom_pose, const double* nom_dim, const double* sample_offset,
+                              double sample_weight, double* X_out, double* J_out, int32_t* iters_out,
+                              int32_t* status_out, uint32_t flags);
+int cilqr_solve_batch_sampled_device(cilqr_handle* h, void* stream, int B, int N, int n_obs, int n_samples,
+                                     const double* x0, double* U, const double* poly, const double* xplan_fl,
+                                     const double* nom_pose, const double* nom_dim, const double* sample_offset,
+                                     double sample_weight, double* X_out, double* J_out, int32_t* iters_out,
+                                     int32_t* status_out, uint32_t flags);
+
 /* Local min-cost selection over a batch resident on the device (strict-< first-minimum tie-break, as in
  * I/Constraints.cpp:50): writes {J_min, (double)index} to out_pair (device, 2 doubles).  The cross-GPU step
  * is one all-gather of these 16-byte pairs (RCCL), done by the caller's communicator. */

@@ -702,3 +702,53 @@ def test_config5_shard_full_size_properties(cilqr, oracle):
     subt = {k: (v[:64] if isinstance(v, np.ndarray) else v) for k, v in sct.items()}
     _compare({k: v[:64] for k, v in gott.items()}, _oracle_batch(oracle, N, subt), TIGHT, "c5 streamed obstacle")
     assert np.isfinite(got["U"]).all() and (got["iters"] >= 1).all()
+
+
+# ---- sampled obstacles in compact form (BASELINE config 3) -----------------------------------------------------------------
+def test_sampled_obstacles_match_oracle_and_materialised_call(cilqr, oracle):
+    """cilqr_solve_batch_sampled: 8 moving obstacles x 32 pose samples given as nominal trajectories + offsets, against
+    (a) the oracle on the materialised 256-obstacle scene (the reference's own Obstacle path with w_obstacle = 1/32,
+    SURVEY §8c) and (b) the product's materialised call.  Sample headings come from angle addition and the semi-axes from
+    refined reciprocals, so (b) is equality to TIGHT, not bit for bit.  Ragged shapes: n_obs = 3, S = 5, N = 30."""
+    from cilqr_amd import scenes
+    p = cilqr.default_params(50)
+    sc = scenes.make_c3(96, p)
+    s = cilqr.Solver(p, max_batch=96, max_horizon=50, max_obstacles=256, device=0)
+    try:
+        got = s.solve_batch_sampled(50, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["nom_pose"], sc["nom_dim"],
+                                    sc["offsets"], sc["sample_weight"])
+        mat = _gpu_batch(s, sc)
+        # an offset of exactly zero in every sample must reproduce the nominal obstacle counted S times
+        z = s.solve_batch_sampled(50, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["nom_pose"], sc["nom_dim"],
+                                  np.zeros_like(sc["offsets"]), sc["sample_weight"])
+        nominal = s.solve_batch(50, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["nom_pose"], sc["nom_dim"],
+                                np.full((96, 8), 1.0))  # weight 32 x 1/32
+        with pytest.raises(cilqr.CilqrError, match="-1"):  # one sample is not a sampled scene
+            s.solve_batch_sampled(50, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["nom_pose"], sc["nom_dim"],
+                                  sc["offsets"][:, :, :1], 1.0)
+    finally:
+        s.close()
+    want = _oracle_batch(oracle, 50, sc)
+    _compare(got, want, TIGHT, "sampled vs oracle")
+    _compare(got, mat, TIGHT, "sampled vs materialised")
+    _compare(z, nominal, TIGHT, "zero offsets vs nominal")
+    # ragged: 3 obstacles x 5 samples, N = 30
+    p30 = cilqr.default_params(30)
+    rng = np.random.default_rng(8)
+    base = scenes.make_static(16, 30, 3, p30, 77)
+    off = rng.normal(0.0, 1.0, (16, 3, 5, 3)) * np.array([0.3, 0.3, 0.05])
+    pose = base["obs_pose"].reshape(16, 3, 1, 30, 4).repeat(5, axis=2).copy()
+    pose[..., 0] += off[..., 0][..., None]
+    pose[..., 1] += off[..., 1][..., None]
+    pose[..., 3] += off[..., 2][..., None]
+    dim = base["obs_dim"].reshape(16, 3, 1, 30, 2).repeat(5, axis=2)
+    s = cilqr.Solver(p30, max_batch=16, max_horizon=30, max_obstacles=15, device=0)
+    try:
+        got = s.solve_batch_sampled(30, base["x0"], base["U"], base["poly"], base["xplan_fl"], base["obs_pose"], base["obs_dim"],
+                                    off, 0.2)
+    finally:
+        s.close()
+    po = oracle.default_params(30)
+    want = oracle.solve_batch(po, 30, 15, base["x0"], base["U"], base["poly"], base["xplan_fl"], pose.reshape(16, 15, 120),
+                              dim.reshape(16, 15, 60), np.full((16, 15), 0.2), threads=min(16, oracle.max_threads()))
+    _compare(got, want, TIGHT, "sampled ragged")

@@ -19,7 +19,7 @@ EXIT_TOLERANCE, EXIT_LAMBDA_MAX, EXIT_MAX_ITER, EXIT_NUMERIC = 0, 1, 2, 3
 # every symbol include/cilqr.h declares
 ABI_SYMBOLS = (
     "cilqr_params_default", "cilqr_abi_version", "cilqr_last_error", "cilqr_default_control_seq",
-    "cilqr_local_plan", "cilqr_local_plan_batch", "cilqr_local_plan_batch_device", "cilqr_create", "cilqr_destroy", "cilqr_solve_batch", "cilqr_solve_batch_device",
+    "cilqr_local_plan", "cilqr_local_plan_batch", "cilqr_local_plan_batch_device", "cilqr_create", "cilqr_destroy", "cilqr_solve_batch", "cilqr_solve_batch_device", "cilqr_solve_batch_sampled", "cilqr_solve_batch_sampled_device",
     "cilqr_argmin_device", "cilqr_wait", "cilqr_set_diag_buffer", "cilqr_debug_quu_inverse", "cilqr_debug_blur_ellipse", "cilqr_warp_costmap", "cilqr_warp_costmap_device", "cilqr_blur_costmap", "cilqr_blur_costmap_device", "cilqr_map_geom_set",
     "cilqr_occupancy_to_layer", "cilqr_occupancy_to_layer_device", "cilqr_layer_to_occupancy", "cilqr_layer_to_occupancy_device",
     "cilqr_costmap_frame_device",
@@ -166,6 +166,34 @@ class Solver:
                                        _p(obs_dim), _p(obs_weight), _p(X), _p(J), _p(iters, _ip), _p(status, _ip),
                                        C.c_uint32(flags)))
         return dict(U=U, X=X, J=J, iters=iters, status=status)
+
+    def solve_batch_sampled(self, N, x0, U, poly, xplan_fl, nom_pose, nom_dim, offsets, weight, flags=0):
+        """Sampled obstacles in compact form: nom_pose (B, n_obs, 4N), nom_dim (B, n_obs, 2N), offsets (B, n_obs, S, 3)."""
+        x0 = _np64(x0).reshape(-1, 4)
+        B = x0.shape[0]
+        U = _np64(U).reshape(B, 2 * N).copy()
+        poly = _np64(poly).reshape(B, POLY)
+        xplan_fl = _np64(xplan_fl).reshape(B, 2)
+        offsets = _np64(offsets)
+        n_obs, S = offsets.shape[1], offsets.shape[2]
+        nom_pose = _np64(nom_pose).reshape(B, n_obs, 4 * N)
+        nom_dim = _np64(nom_dim).reshape(B, n_obs, 2 * N)
+        offsets = offsets.reshape(B, n_obs, S, 3)
+        X = np.zeros((B, 4 * (N + 1)))
+        J = np.zeros(B)
+        iters = np.zeros(B, dtype=np.int32)
+        status = np.zeros(B, dtype=np.int32)
+        _check(lib().cilqr_solve_batch_sampled(self._h, B, int(N), int(n_obs), int(S), _p(x0), _p(U), _p(poly), _p(xplan_fl),
+                                               _p(nom_pose), _p(nom_dim), _p(offsets), C.c_double(weight), _p(X), _p(J),
+                                               _p(iters, _ip), _p(status, _ip), C.c_uint32(flags)))
+        return dict(U=U, X=X, J=J, iters=iters, status=status)
+
+    def solve_batch_sampled_device(self, stream, B, N, n_obs, n_samples, x0, U, poly, xplan_fl, nom_pose, nom_dim, offsets, weight,
+                                   X_out, J_out, iters_out, status_out, flags=0):
+        _check(lib().cilqr_solve_batch_sampled_device(self._h, _vp(stream), int(B), int(N), int(n_obs), int(n_samples), _vp(x0),
+                                                      _vp(U), _vp(poly), _vp(xplan_fl), _vp(nom_pose), _vp(nom_dim), _vp(offsets),
+                                                      C.c_double(weight), _vp(X_out), _vp(J_out), _vp(iters_out), _vp(status_out),
+                                                      C.c_uint32(flags)))
 
     # ---- device-pointer entry point (asynchronous on `stream`) ----
     def solve_batch_device(self, stream, B, N, M, x0, U, poly, xplan_fl, obs_pose, obs_dim, obs_weight, X_out, J_out,

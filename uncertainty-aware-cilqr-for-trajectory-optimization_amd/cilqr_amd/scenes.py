@@ -124,7 +124,10 @@ def make_c3(B=4096, params=None, local_plan=None, n_dyn=8, n_samples=32):
     dims = np.repeat(dim[:, :, None, :, :], n_samples, axis=2)
     w = np.full((B, M), 1.0 / n_samples)
     return dict(N=N, M=M, x0=x0, U=_default_U(B, N), poly=poly, xplan_fl=xplan,
-                obs_pose=poses.reshape(B, M, 4 * N), obs_dim=dims.reshape(B, M, 2 * N), obs_weight=w)
+                obs_pose=poses.reshape(B, M, 4 * N), obs_dim=dims.reshape(B, M, 2 * N), obs_weight=w,
+                # the same obstacles in compact form (cilqr_solve_batch_sampled): nominal trajectories + per-sample offsets
+                nom_pose=pose.reshape(B, n_dyn, 4 * N), nom_dim=dim.reshape(B, n_dyn, 2 * N), offsets=off,
+                sample_weight=1.0 / n_samples)
 
 
 def make_c4(seed=SEED0 + 4, size=1024):

@@ -40,7 +40,7 @@ struct cilqr_handle {
   int max_batch, max_horizon, max_obstacles;
   hipStream_t stream;
   // device staging for the host-pointer entry points
-  double *d_x0, *d_U, *d_poly, *d_xplan, *d_obs_pose, *d_obs_dim, *d_obs_w, *d_X, *d_J;
+  double *d_x0, *d_U, *d_poly, *d_xplan, *d_obs_pose, *d_obs_dim, *d_obs_w, *d_samp_off, *d_X, *d_J;
   int32_t *d_iters, *d_status;
   // workspace
   double* d_obs_tab;
@@ -174,6 +174,7 @@ int cilqr_create(const cilqr_params* p, int max_batch, int max_horizon, int max_
   if (err == hipSuccess) err = dmalloc(&h->d_obs_pose, B * M * N * 4);
   if (err == hipSuccess) err = dmalloc(&h->d_obs_dim, B * M * N * 2);
   if (err == hipSuccess) err = dmalloc(&h->d_obs_w, B * M);
+  if (err == hipSuccess) err = dmalloc(&h->d_samp_off, B * M * 3);
   if (err == hipSuccess) err = dmalloc(&h->d_X, B * 4 * (N + 1));
   if (err == hipSuccess) err = dmalloc(&h->d_J, B);
   if (err == hipSuccess) err = dmalloc(&h->d_iters, B);
@@ -197,7 +198,7 @@ int cilqr_destroy(cilqr_handle* h) {
   if (!h) return CILQR_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void* ptrs[] = {h->d_x0, h->d_U, h->d_poly, h->d_xplan, h->d_obs_pose, h->d_obs_dim, h->d_obs_w, h->d_X, h->d_J,
+  void* ptrs[] = {h->d_x0, h->d_U, h->d_poly, h->d_xplan, h->d_obs_pose, h->d_obs_dim, h->d_obs_w, h->d_samp_off, h->d_X, h->d_J,
                   h->d_iters, h->d_status, h->d_obs_tab, h->d_ws, h->d_redo, h->d_pair, h->d_src, h->d_dst, h->d_bbox, h->d_oob};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -261,6 +262,7 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
   a.x0 = x0; a.U = U; a.poly = poly; a.xplan_fl = xplan_fl;
   a.obs_pose = obs_pose; a.obs_dim = obs_dim; a.obs_weight = M > 0 ? obs_weight : nullptr;
   a.X_out = X_out; a.J_out = J_out; a.iters_out = iters_out; a.status_out = status_out;
+  a.samp_off = nullptr; a.n_samples = 0; a.samp_w = 0.0;
   a.obs_tab = h->d_obs_tab;
   a.redo = h->d_redo;
   a.diag = h->diag;
@@ -305,6 +307,67 @@ int cilqr_solve_batch(cilqr_handle* h, int B, int N, int M, const double* x0, do
   }
   rc = cilqr_solve_batch_device(h, s, B, N, M, h->d_x0, h->d_U, h->d_poly, h->d_xplan, h->d_obs_pose, h->d_obs_dim,
                                 (M > 0 && obs_weight) ? h->d_obs_w : nullptr, h->d_X, h->d_J, h->d_iters, h->d_status, flags);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(U, h->d_U, b * 2 * n * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(X_out, h->d_X, b * 4 * (n + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (J_out) HIP_TRY(hipMemcpyAsync(J_out, h->d_J, b * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (iters_out) HIP_TRY(hipMemcpyAsync(iters_out, h->d_iters, b * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  if (status_out) HIP_TRY(hipMemcpyAsync(status_out, h->d_status, b * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return CILQR_OK;
+}
+
+int cilqr_solve_batch_sampled_device(cilqr_handle* h, void* stream, int B, int N, int n_obs, int n_samples, const double* x0,
+                                     double* U, const double* poly, const double* xplan_fl, const double* nom_pose,
+                                     const double* nom_dim, const double* sample_offset, double sample_weight, double* X_out,
+                                     double* J_out, int32_t* iters_out, int32_t* status_out, uint32_t flags) {
+  if (n_obs < 1 || n_samples < 2) return fail(CILQR_ERR_ARG, "cilqr_solve_batch_sampled: needs n_obs >= 1 and n_samples >= 2");
+  if ((long)n_obs * n_samples > 1 << 20) return fail(CILQR_ERR_ARG, "cilqr_solve_batch_sampled: n_obs * n_samples too large");
+  int rc = check_sizes(h, B, N, n_obs * n_samples);  // the equivalent materialised obstacle count
+  if (rc) return rc;
+  if (B == 0) return CILQR_OK;
+  if (!x0 || !U || !poly || !xplan_fl || !X_out || !nom_pose || !nom_dim || !sample_offset)
+    return fail(CILQR_ERR_ARG, "cilqr_solve_batch_sampled: null required pointer");
+  if (cilqr::solve_lds_bytes(N, h->kp.n_samples) + cilqr::solve_sampled_lds_bytes(n_obs, n_samples) > 64 * 1024)
+    return fail(CILQR_ERR_UNSUPPORTED, "cilqr_solve_batch_sampled: n_obs * n_samples offset records do not fit LDS beside the solve");
+  cilqr::SolveArgs a;
+  a.x0 = x0; a.U = U; a.poly = poly; a.xplan_fl = xplan_fl;
+  a.obs_pose = nom_pose; a.obs_dim = nom_dim; a.obs_weight = nullptr;
+  a.X_out = X_out; a.J_out = J_out; a.iters_out = iters_out; a.status_out = status_out;
+  a.samp_off = sample_offset; a.n_samples = n_samples; a.samp_w = sample_weight;
+  a.obs_tab = h->d_obs_tab;  // n_obs·N·8 doubles per solve ≤ the n_obs·n_samples·N·6 reserved for the materialised form
+  a.redo = h->d_redo;
+  a.diag = h->diag;
+  a.B = B; a.N = N; a.M = n_obs; a.flags = flags;
+  a.kp = h->kp;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(cilqr::launch_solve_wave(a, (hipStream_t)stream));  // the LDS-resident family at every batch size
+  return CILQR_OK;
+}
+
+int cilqr_solve_batch_sampled(cilqr_handle* h, int B, int N, int n_obs, int n_samples, const double* x0, double* U,
+                              const double* poly, const double* xplan_fl, const double* nom_pose, const double* nom_dim,
+                              const double* sample_offset, double sample_weight, double* X_out, double* J_out,
+                              int32_t* iters_out, int32_t* status_out, uint32_t flags) {
+  if (n_obs < 1 || n_samples < 2) return fail(CILQR_ERR_ARG, "cilqr_solve_batch_sampled: needs n_obs >= 1 and n_samples >= 2");
+  if ((long)n_obs * n_samples > 1 << 20) return fail(CILQR_ERR_ARG, "cilqr_solve_batch_sampled: n_obs * n_samples too large");
+  int rc = check_sizes(h, B, N, n_obs * n_samples);
+  if (rc) return rc;
+  if (B == 0) return CILQR_OK;
+  if (!x0 || !U || !poly || !xplan_fl || !X_out || !nom_pose || !nom_dim || !sample_offset)
+    return fail(CILQR_ERR_ARG, "cilqr_solve_batch_sampled: null required pointer");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  const size_t b = B, n = N, m = n_obs;
+  HIP_TRY(hipMemcpyAsync(h->d_x0, x0, b * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->d_U, U, b * 2 * n * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->d_poly, poly, b * CILQR_POLY_COEFFS * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->d_xplan, xplan_fl, b * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->d_obs_pose, nom_pose, b * m * n * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->d_obs_dim, nom_dim, b * m * n * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->d_samp_off, sample_offset, b * m * n_samples * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+  rc = cilqr_solve_batch_sampled_device(h, s, B, N, n_obs, n_samples, h->d_x0, h->d_U, h->d_poly, h->d_xplan, h->d_obs_pose,
+                                        h->d_obs_dim, h->d_samp_off, sample_weight, h->d_X, h->d_J, h->d_iters, h->d_status, flags);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(U, h->d_U, b * 2 * n * sizeof(double), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(X_out, h->d_X, b * 4 * (n + 1) * sizeof(double), hipMemcpyDeviceToHost, s));

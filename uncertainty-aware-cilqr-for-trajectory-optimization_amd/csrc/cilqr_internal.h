@@ -39,7 +39,10 @@ struct SolveArgs {
   double* J_out;        // may be null
   int32_t* iters_out;   // may be null
   int32_t* status_out;  // may be null
-  double* obs_tab;      // workspace: [B][M][6][N]
+  const double* samp_off;  // sampled obstacles only: [B][M][n_samples][3] = (dx, dy, dtheta); then obs_pose/obs_dim are the
+  int32_t n_samples;       // nominal trajectories of the M obstacles, every sample weighs samp_w, and the wavefront family runs.
+  double samp_w;           // n_samples == 0: ordinary obstacles
+  double* obs_tab;      // workspace: [B][M][N][6] (sampled: [B][M][N][8])
   int32_t* redo;        // workspace: [B] hand-over flags from the fast kernel to the general kernel
   unsigned long long* diag;  // null, or [B][8] phase cycle totals (diagnostic instantiation)
   int32_t B, N, M;
@@ -51,6 +54,8 @@ struct SolveArgs {
 // One wavefront per solve, LDS-resident (cilqr_solve.hip).
 hipError_t launch_solve_wave(const SolveArgs& a, hipStream_t stream);
 size_t solve_lds_bytes(int N, int n_samples);
+size_t solve_sampled_lds_bytes(int n_obs, int n_samples);   // additional LDS of the sampled-obstacle mode
+size_t solve_sampled_tab_doubles(int n_obs, int N);         // its workspace need per solve (in obs_tab)
 // G lanes per solve (G in {1,2,4,8,16,32}), workspace `ws` of solve_groups_ws_doubles(B, N) doubles (cilqr_solve_groups.hip).
 hipError_t launch_solve_groups(const SolveArgs& a, int G, double* ws, hipStream_t stream);
 size_t solve_groups_ws_doubles(int B, int N);

@@ -68,10 +68,73 @@ struct TabObstacles {  // obstacle accessor over the [m][t][field] table (LDS or
   }
 };
 
-// Phase L.  Returns this lane's partial of J over its timesteps.
+struct TabSource {  // every obstacle has its own table row
+  const double* tab;
+  const double* wts;
+  int N;
+  double w_default;
+  __device__ __forceinline__ TabObstacles at(int t) const { return TabObstacles{tab + (size_t)t * TABF, wts, N, w_default}; }
+};
+
+// Sampled obstacles (BASELINE config 3: n_obs moving obstacles × S pose samples, sample = nominal trajectory + a constant
+// (dx, dy, dtheta)): entry (o, s) at step t is derived from the nominal record of (o, t) and the offset record of (o, s)
+// instead of being read from a materialised n_obs·S·N table — that table is 614 KB per solve at config 3 and was
+// re-streamed from HBM by every iteration (measured ≈ 20 GB per launch of 4096 solves).  The nominal records (8 doubles per
+// (o, t)) stay in global memory and are read once per obstacle and iteration; the offset records live in LDS and are read
+// at a wave-uniform address.  cos/sin of the sample heading come from the angle-addition formulas.
+constexpr int NOMF = 8;  // x, y, cos, sin, v·t_safe, half-length + margins, half-width + margins, pad
+constexpr int OFFF = 4;  // dx, dy, cos(dtheta), sin(dtheta)
+struct SampledObstacles {
+  const double* nom;  // this lane's step: record of obstacle 0; obstacle stride N·NOMF
+  const double* off;  // LDS [o][s][OFFF]
+  int N, S, n_obs;
+  double w;
+  int o, s;
+  double x, y, c0, s0, vt, ha, hb;         // nominal record in use
+  double nx, ny, nc0, ns0, nvt, nha, nhb;  // the next obstacle's, requested one obstacle (S entries) ahead
+  __device__ __forceinline__ void request(int oo) {
+    const double2* p = reinterpret_cast<const double2*>(nom + (size_t)oo * NOMF * N);
+    const double2 a = p[0], b = p[1], c = p[2], d = p[3];
+    nx = a.x; ny = a.y; nc0 = b.x; ns0 = b.y; nvt = c.x; nha = c.y; nhb = d.x;
+  }
+  // called with m = 0, 1, 2, … in order (lin_step does)
+  __device__ __forceinline__ void operator()(int, ObsEntry& e, double& wout) {
+    if (s == 0) {
+      x = nx; y = ny; c0 = nc0; s0 = ns0; vt = nvt; ha = nha; hb = nhb;
+      if (o + 1 < n_obs) request(o + 1);
+    }
+    const double2* q = reinterpret_cast<const double2*>(off + ((size_t)o * S + s) * OFFF);
+    const double2 d = q[0], r = q[1];
+    e.co = c0 * r.x - s0 * r.y;
+    e.so = s0 * r.x + c0 * r.y;
+    const double ra = rcp_newton(ha + fabs(vt * e.co)), rb = rcp_newton(hb + fabs(vt * e.so));  // I/Obstacle.cpp:42-43
+    e.ia2 = ra * ra;
+    e.ib2 = rb * rb;
+    e.ox = x + d.x;
+    e.oy = y + d.y;
+    wout = w;
+    if (++s == S) { s = 0; ++o; }
+  }
+};
+struct SampledSource {
+  const double* nom;
+  const double* off;
+  int N, S, n_obs;
+  double w;
+  __device__ __forceinline__ SampledObstacles at(int t) const {
+    SampledObstacles a;
+    a.nom = nom + (size_t)t * NOMF; a.off = off; a.N = N; a.S = S; a.n_obs = n_obs; a.w = w;
+    a.o = 0; a.s = 0;
+    a.request(0);
+    return a;
+  }
+};
+
+// Phase L.  Returns this lane's partial of J over its timesteps.  M = number of obstacle entries per step.
+template <typename Source>
 __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int lane, const double* samp, int S,
                                             const SampleGrid& grid, const double* X, const double* U, double* rec,
-                                            const double* tab, const double* wts) {
+                                            const Source& src) {
   double Jpart = 0.0;
   for (int t = lane; t < N; t += WAVE) {
     const double* xr = X + t * XR;
@@ -80,7 +143,7 @@ __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int
     const int cs = closest_sample(S, grid, px, py, LdsSamples{samp});
     Rec c;
     Jpart += lin_step(kp, px, py, xr[2], xr[4], xr[5], U[2 * t], U[2 * t + 1], xn[2], xn[4], xn[5], samp[2 * cs],
-                      samp[2 * cs + 1], M, TabObstacles{tab + (size_t)t * TABF, wts, N, kp.w_obstacle}, c);
+                      samp[2 * cs + 1], M, src.at(t), c);
     double* r = rec + t * REC;
     r[0] = c.lx0; r[1] = c.lx1; r[2] = c.lx2; r[3] = c.l00; r[4] = c.l01; r[5] = c.l11;
     r[6] = c.lu0; r[7] = c.lu1; r[8] = c.luu0; r[9] = c.luu1;
@@ -233,13 +296,13 @@ __device__ __forceinline__ bool rollout_fast(const KParams& kp, int N, const dou
 
 // DIAG: per-solve shader-clock totals by phase, written to a.diag[b][8] = {prologue, L, R, F, epilogue, L count, R count,
 // total}.  A separate instantiation so that the production kernel carries no stamps.
-// TABLDS: the obstacle table of the solve lives in LDS (chosen by the launcher when it fits beside the rest at the
-// wanted residency) instead of the global workspace.
+// TAB: where a step's obstacle entries come from — 0: the table in the global workspace; 1: the table in LDS (chosen by the
+// launcher when it fits beside the rest at the wanted residency); 2: sampled obstacles, derived on the fly (SampledObstacles).
 // GENERAL: false = the production kernel: branch-free fast passes.  A solve that meets anything the fast passes do not
 // cover (Q_uu not positive semi-definite or not finite; a heading beyond the in-loop sincos range) stops WITHOUT touching
 // its outputs and sets a.redo[b]; the GENERAL = true kernel, launched right behind on the same stream, redoes exactly
 // those solves from their untouched inputs with the branching passes and returns at once for all others.
-template <bool DIAG, bool TABLDS, bool GENERAL>
+template <bool DIAG, int TAB, bool GENERAL>
 __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   unsigned long long tk0 = 0, tk = 0, c_pro = 0, c_L = 0, c_R = 0, c_F = 0, n_L = 0, n_R = 0;
   if (DIAG) tk0 = tk = __builtin_readcyclecounter();
@@ -254,6 +317,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   const int lane = threadIdx.x;
   const KParams kp = a.kp;
   const int N = a.N, M = a.M, S = kp.n_samples;
+  const int n_entries = TAB == 2 ? M * a.n_samples : M;  // obstacle entries per step
   if (b >= a.B) return;
   if (GENERAL && a.redo[b] == 0) return;
 
@@ -264,7 +328,8 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   double* Ub = Ua + 2 * N;
   double* rec = Ub + 2 * N;
   double* kK = rec + N * REC;
-  double* tab = TABLDS ? kK + N * KR : a.obs_tab + (size_t)b * M * TABF * N;
+  double* tab = TAB == 1 ? kK + N * KR : a.obs_tab + (size_t)b * M * (TAB == 2 ? NOMF : TABF) * N;
+  double* off = kK + N * KR;  // TAB == 2: offset records [o][s][OFFF]
 
   // ---- prologue -------------------------------------------------------------------------------------------
   SampleGrid grid;
@@ -276,12 +341,36 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   double* Ug = a.U + (size_t)b * 2 * N;
   for (int i = lane; i < 2 * N; i += WAVE) Ua[i] = Ug[i];
 
-  const double* wts = a.obs_weight ? a.obs_weight + (size_t)b * M : nullptr;
-  for (int m = 0; m < M; ++m) {  // obstacle table, I/Obstacle.cpp:41-62
-    for (int t = lane; t < N; t += WAVE) {
-      const ObsEntry e = make_obs_entry(kp, a.obs_pose + (((size_t)b * M + m) * N + t) * 4, a.obs_dim + (((size_t)b * M + m) * N + t) * 2);
-      double* o = tab + ((size_t)m * N + t) * TABF;
-      o[0] = e.ox; o[1] = e.oy; o[2] = e.co; o[3] = e.so; o[4] = e.ia2; o[5] = e.ib2;
+  const double* wts = (TAB != 2 && a.obs_weight) ? a.obs_weight + (size_t)b * M : nullptr;
+  if (TAB == 2) {
+    for (int m = 0; m < M; ++m) {  // nominal records: what I/Obstacle.cpp:41-62 needs of (obstacle, step) before the sample offset
+      for (int t = lane; t < N; t += WAVE) {
+        const double* pose = a.obs_pose + (((size_t)b * M + m) * N + t) * 4;
+        const double* dim = a.obs_dim + (((size_t)b * M + m) * N + t) * 2;
+        double sn, cs;
+        sincos(pose[3], &sn, &cs);
+        double* o = tab + ((size_t)m * N + t) * NOMF;
+        o[0] = pose[0]; o[1] = pose[1]; o[2] = cs; o[3] = sn; o[4] = pose[2] * kp.t_safe;
+        o[5] = dim[0] / 2.0 + kp.s_safe_a + kp.ego_rad;
+        o[6] = dim[1] / 2.0 + kp.s_safe_b + kp.ego_rad + 1;
+        o[7] = 0.0;
+      }
+    }
+    const int n_off = M * a.n_samples;
+    for (int i = lane; i < n_off; i += WAVE) {
+      const double* q = a.samp_off + ((size_t)b * n_off + i) * 3;
+      double sn, cs;
+      sincos(q[2], &sn, &cs);
+      double* o = off + (size_t)i * OFFF;
+      o[0] = q[0]; o[1] = q[1]; o[2] = cs; o[3] = sn;
+    }
+  } else {
+    for (int m = 0; m < M; ++m) {  // obstacle table, I/Obstacle.cpp:41-62
+      for (int t = lane; t < N; t += WAVE) {
+        const ObsEntry e = make_obs_entry(kp, a.obs_pose + (((size_t)b * M + m) * N + t) * 4, a.obs_dim + (((size_t)b * M + m) * N + t) * 2);
+        double* o = tab + ((size_t)m * N + t) * TABF;
+        o[0] = e.ox; o[1] = e.oy; o[2] = e.co; o[3] = e.so; o[4] = e.ia2; o[5] = e.ib2;
+      }
     }
   }
   __syncthreads();
@@ -317,7 +406,12 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
     ++iters;
     // The reference evaluates backward_pass, forward_pass, then J_new = get_J(X, U) on the CURRENT X, U (:213-217).
     // The linearisation and J share their closest-point searches, so they are computed together, first.
-    J_new = readfirstlane_f64(wave_sum(linearize(kp, N, M, lane, samp, S, grid, Xc, Uc, rec, tab, wts)));
+    {
+      double part;
+      if (TAB == 2) part = linearize(kp, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, SampledSource{tab, off, N, a.n_samples, M, a.samp_w});
+      else part = linearize(kp, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, TabSource{tab, wts, N, kp.w_obstacle});
+      J_new = readfirstlane_f64(wave_sum(part));
+    }
     j_valid = true;
     __syncthreads();
     CILQR_STAMP(c_L)
@@ -404,10 +498,10 @@ __global__ void quu_inverse_kernel(int n, const double* q, const double* lamb, d
   out[4 * i] = ok ? i00 : nan; out[4 * i + 1] = ok ? i01 : nan; out[4 * i + 2] = ok ? i01 : nan; out[4 * i + 3] = ok ? i11 : nan;
 }
 
-template <bool DIAG, bool TABLDS>
+template <bool DIAG, int TAB>
 void launch_pair(const SolveArgs& a, size_t lds, hipStream_t stream) {
-  hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, TABLDS, false>), dim3(a.B), dim3(WAVE), lds, stream, a);
-  hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, TABLDS, true>), dim3(a.B), dim3(WAVE), lds, stream, a);
+  hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, TAB, false>), dim3(a.B), dim3(WAVE), lds, stream, a);
+  hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, TAB, true>), dim3(a.B), dim3(WAVE), lds, stream, a);
 }
 
 }  // namespace
@@ -416,6 +510,9 @@ size_t solve_lds_bytes(int N, int n_samples) {
   const size_t doubles = 2 * (size_t)n_samples + 2 * (size_t)(N + 1) * XR + 2 * (size_t)2 * N + (size_t)N * REC + (size_t)N * KR;
   return doubles * sizeof(double);
 }
+
+size_t solve_sampled_lds_bytes(int n_obs, int n_samples) { return (size_t)n_obs * n_samples * OFFF * sizeof(double); }
+size_t solve_sampled_tab_doubles(int n_obs, int N) { return (size_t)n_obs * NOMF * N; }
 
 hipError_t launch_quu_inverse(int n, const double* q, const double* lamb, double* out, int general, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
@@ -428,14 +525,19 @@ hipError_t launch_solve_wave(const SolveArgs& a, hipStream_t stream) {
   size_t lds = solve_lds_bytes(a.N, a.kp.n_samples);
   // Keep the obstacle table in LDS while a workgroup stays within 32 KiB (≥ 5 solves resident per CU of 160 KiB).
   const size_t tab_bytes = (size_t)a.M * TABF * a.N * sizeof(double);
-  const bool tab_lds = a.M > 0 && lds + tab_bytes <= 32 * 1024;
+  const bool tab_lds = a.n_samples == 0 && a.M > 0 && lds + tab_bytes <= 32 * 1024;
   if (tab_lds) lds += tab_bytes;
-  if (a.diag) {
-    if (tab_lds) launch_pair<true, true>(a, lds, stream);
-    else launch_pair<true, false>(a, lds, stream);
+  if (a.n_samples > 0) {  // sampled obstacles: offset records in LDS, nominal records in the global workspace
+    lds += solve_sampled_lds_bytes(a.M, a.n_samples);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;  // checked by the caller
+    if (a.diag) launch_pair<true, 2>(a, lds, stream);
+    else launch_pair<false, 2>(a, lds, stream);
+  } else if (a.diag) {
+    if (tab_lds) launch_pair<true, 1>(a, lds, stream);
+    else launch_pair<true, 0>(a, lds, stream);
   } else {
-    if (tab_lds) launch_pair<false, true>(a, lds, stream);
-    else launch_pair<false, false>(a, lds, stream);
+    if (tab_lds) launch_pair<false, 1>(a, lds, stream);
+    else launch_pair<false, 0>(a, lds, stream);
   }
   return hipGetLastError();
 }
