@@ -53,7 +53,7 @@ extern "C" {
 #define CILQR_NX 4
 #define CILQR_NU 2
 #define CILQR_POLY_COEFFS 6   /* poly_order + 1, I/Parameters.cpp:7 */
-#define CILQR_MAX_HORIZON 128
+#define CILQR_MAX_HORIZON 384  /* per-solve arrays of the LDS-resident family at the default sample count: 132 KiB of 160 */
 #define CILQR_ABI_VERSION 1
 
 /* Field-for-field POD mirror of class Parameters (I/Parameters.h:5-91) — only the fields the

@@ -780,7 +780,8 @@ int oracle_local_plan(const cilqr_params* p, const double* path, int P, const do
     if (t < md) { md = t; mi = i; }
   }
   int n = (P - mi) < p->num_of_local_wpts ? (P - mi) : p->num_of_local_wpts;
-  double* xs = (double*)malloc(sizeof(double) * 2 * (size_t)n);
+  if (n < 1) return 0;  /* P >= 1 and num_of_local_wpts >= 1 are the caller's contract */
+  double* xs = (double*)calloc(2 * (size_t)n, sizeof(double));
   double* ys = xs + n;
   for (int i = 0; i < n; i++) { xs[i] = path[2 * (mi + i)]; ys[i] = path[2 * (mi + i) + 1]; }
   oracle_polyfit(xs, ys, n, p->poly_order, coeffs);

@@ -752,3 +752,31 @@ def test_sampled_obstacles_match_oracle_and_materialised_call(cilqr, oracle):
     want = oracle.solve_batch(po, 30, 15, base["x0"], base["U"], base["poly"], base["xplan_fl"], pose.reshape(16, 15, 120),
                               dim.reshape(16, 15, 60), np.full((16, 15), 0.2), threads=min(16, oracle.max_threads()))
     _compare(got, want, TIGHT, "sampled ragged")
+
+
+def test_long_horizons(cilqr, oracle):
+    """Horizons whose per-solve arrays need more than the default 64 KiB of dynamic LDS (N = 256: ≈ 90 KiB) run after an
+    explicit opt-in.  Beyond CILQR_MAX_HORIZON cilqr_create refuses; and a sampled-obstacle call whose offset records do not
+    fit the CU's 160 KiB beside the solve is refused with CILQR_ERR_UNSUPPORTED — never a failed launch."""
+    from cilqr_amd import scenes
+    for N, M, B in ((150, 2, 6), (256, 3, 5)):
+        p = cilqr.default_params(N)
+        sc = scenes.make_static(B, N, M, p, 90 + N)
+        s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M, device=0)
+        try:
+            got = _gpu_batch(s, sc)
+        finally:
+            s.close()
+        _compare(got, _oracle_batch(oracle, N, sc), 1e-8, "N%d" % N)
+    with pytest.raises(cilqr.CilqrError, match="-1"):
+        cilqr.Solver(cilqr.default_params(600), max_batch=2, max_horizon=600, max_obstacles=0, device=0)
+    # sampled obstacles: 8 x 256 offset records (64 KB) beside a 384-step solve (132 KB) do not fit one CU's LDS
+    p = cilqr.default_params(384)
+    sc = scenes.make_static(2, 384, 8, p, 3)
+    s = cilqr.Solver(p, max_batch=2, max_horizon=384, max_obstacles=2048, device=0)
+    try:
+        with pytest.raises(cilqr.CilqrError, match="-4"):
+            s.solve_batch_sampled(384, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"],
+                                  np.zeros((2, 8, 256, 3)), 1.0 / 256)
+    finally:
+        s.close()

@@ -280,6 +280,9 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
     G = 32;
     while (G > 1 && (long)G * B > 65536) G >>= 1;
   }
+  if (G == 64 && cilqr::solve_lds_bytes(N, h->kp.n_samples) > cilqr::SOLVE_LDS_MAX)
+    return fail(CILQR_ERR_UNSUPPORTED, "cilqr_solve_batch: horizon %d needs %zu bytes of LDS per solve (limit %zu)", N,
+                cilqr::solve_lds_bytes(N, h->kp.n_samples), cilqr::SOLVE_LDS_MAX);
   if (G == 64) HIP_TRY(cilqr::launch_solve_wave(a, (hipStream_t)stream));
   else HIP_TRY(cilqr::launch_solve_groups(a, G, h->d_ws, (hipStream_t)stream));
   return CILQR_OK;
@@ -328,7 +331,7 @@ int cilqr_solve_batch_sampled_device(cilqr_handle* h, void* stream, int B, int N
   if (B == 0) return CILQR_OK;
   if (!x0 || !U || !poly || !xplan_fl || !X_out || !nom_pose || !nom_dim || !sample_offset)
     return fail(CILQR_ERR_ARG, "cilqr_solve_batch_sampled: null required pointer");
-  if (cilqr::solve_lds_bytes(N, h->kp.n_samples) + cilqr::solve_sampled_lds_bytes(n_obs, n_samples) > 64 * 1024)
+  if (cilqr::solve_lds_bytes(N, h->kp.n_samples) + cilqr::solve_sampled_lds_bytes(n_obs, n_samples) > cilqr::SOLVE_LDS_MAX)
     return fail(CILQR_ERR_UNSUPPORTED, "cilqr_solve_batch_sampled: n_obs * n_samples offset records do not fit LDS beside the solve");
   cilqr::SolveArgs a;
   a.x0 = x0; a.U = U; a.poly = poly; a.xplan_fl = xplan_fl;

@@ -54,6 +54,7 @@ struct SolveArgs {
 // One wavefront per solve, LDS-resident (cilqr_solve.hip).
 hipError_t launch_solve_wave(const SolveArgs& a, hipStream_t stream);
 size_t solve_lds_bytes(int N, int n_samples);
+constexpr size_t SOLVE_LDS_MAX = 160 * 1024;  // LDS of one CU: the horizon bound of the wavefront family
 size_t solve_sampled_lds_bytes(int n_obs, int n_samples);   // additional LDS of the sampled-obstacle mode
 size_t solve_sampled_tab_doubles(int n_obs, int N);         // its workspace need per solve (in obs_tab)
 // G lanes per solve (G in {1,2,4,8,16,32}), workspace `ws` of solve_groups_ws_doubles(B, N) doubles (cilqr_solve_groups.hip).

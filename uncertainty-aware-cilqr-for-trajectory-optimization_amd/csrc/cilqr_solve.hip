@@ -499,9 +499,18 @@ __global__ void quu_inverse_kernel(int n, const double* q, const double* lamb, d
 }
 
 template <bool DIAG, int TAB>
-void launch_pair(const SolveArgs& a, size_t lds, hipStream_t stream) {
+hipError_t launch_pair(const SolveArgs& a, size_t lds, hipStream_t stream) {
+  if (lds > 64 * 1024) {  // long horizons: opt in to more than the default 64 KiB of dynamic LDS (the CU has 160 KiB)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cilqr_solve_kernel<DIAG, TAB, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cilqr_solve_kernel<DIAG, TAB, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
   hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, TAB, false>), dim3(a.B), dim3(WAVE), lds, stream, a);
   hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, TAB, true>), dim3(a.B), dim3(WAVE), lds, stream, a);
+  return hipGetLastError();
 }
 
 }  // namespace
@@ -529,17 +538,12 @@ hipError_t launch_solve_wave(const SolveArgs& a, hipStream_t stream) {
   if (tab_lds) lds += tab_bytes;
   if (a.n_samples > 0) {  // sampled obstacles: offset records in LDS, nominal records in the global workspace
     lds += solve_sampled_lds_bytes(a.M, a.n_samples);
-    if (lds > 64 * 1024) return hipErrorInvalidValue;  // checked by the caller
-    if (a.diag) launch_pair<true, 2>(a, lds, stream);
-    else launch_pair<false, 2>(a, lds, stream);
-  } else if (a.diag) {
-    if (tab_lds) launch_pair<true, 1>(a, lds, stream);
-    else launch_pair<true, 0>(a, lds, stream);
-  } else {
-    if (tab_lds) launch_pair<false, 1>(a, lds, stream);
-    else launch_pair<false, 0>(a, lds, stream);
+    if (lds > SOLVE_LDS_MAX) return hipErrorInvalidValue;  // checked by the caller
+    return a.diag ? launch_pair<true, 2>(a, lds, stream) : launch_pair<false, 2>(a, lds, stream);
   }
-  return hipGetLastError();
+  if (lds > SOLVE_LDS_MAX) return hipErrorInvalidValue;  // checked by the caller
+  if (a.diag) return tab_lds ? launch_pair<true, 1>(a, lds, stream) : launch_pair<true, 0>(a, lds, stream);
+  return tab_lds ? launch_pair<false, 1>(a, lds, stream) : launch_pair<false, 0>(a, lds, stream);
 }
 
 }  // namespace cilqr
