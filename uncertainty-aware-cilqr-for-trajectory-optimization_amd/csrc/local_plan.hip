@@ -47,6 +47,8 @@ struct LdsStore {
   __device__ int& order(int j) { return n[(cols + j) * LPB]; }
 };
 
+// RM: rows of the fit known at compile time (num_of_local_wpts; 20 in the reference) → unrolled row loops; 0 → plain loops.
+template <int RM>
 __global__ __launch_bounds__(LPB) void local_plan_kernel(LocalPlanArgs a) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -66,6 +68,7 @@ __global__ __launch_bounds__(LPB) void local_plan_kernel(LocalPlanArgs a) {
   double dx = ex - path[0], dy = ey - path[1];
   double best = dx * dx + dy * dy;
   int first = 0;
+#pragma unroll 4
   for (int i = 1; i < a.P; ++i) {
     dx = ex - path[2 * i];
     dy = ey - path[2 * i + 1];
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(LPB) void local_plan_kernel(LocalPlanArgs a) {
   double coeffs[CILQR_POLY_COEFFS];
   {
     // the store's matrix stride is rows_max; the fit works on the leading n rows
-    vandermonde_lstsq(s, n, a.cols, coeffs);
+    vandermonde_lstsq<RM>(s, n, a.cols, coeffs);
   }
   for (int j = 0; j < a.cols; ++j) a.poly[(size_t)b * CILQR_POLY_COEFFS + j] = coeffs[j];
   for (int j = a.cols; j < CILQR_POLY_COEFFS; ++j) a.poly[(size_t)b * CILQR_POLY_COEFFS + j] = 0.0;
@@ -113,7 +116,8 @@ size_t local_plan_lds_bytes(int n_wpts, int cols) {
 hipError_t launch_local_plan(const LocalPlanArgs& a, hipStream_t stream) {
   const size_t lds = local_plan_lds_bytes(a.n_wpts, a.cols);
   if (lds > 64 * 1024) return hipErrorInvalidValue;  // checked against the parameters at cilqr_create
-  local_plan_kernel<<<dim3((a.B + LPB - 1) / LPB), dim3(LPB), lds, stream>>>(a);
+  if (a.n_wpts == 20) local_plan_kernel<20><<<dim3((a.B + LPB - 1) / LPB), dim3(LPB), lds, stream>>>(a);
+  else local_plan_kernel<0><<<dim3((a.B + LPB - 1) / LPB), dim3(LPB), lds, stream>>>(a);
   return hipGetLastError();
 }
 

@@ -34,7 +34,7 @@ void vandermonde_lstsq(const std::vector<double>& x, const std::vector<double>& 
     for (int j = 0; j < cols; ++j) s.m(i, j) = pow(x[i], (double)j);
     s.c(i) = y[i];
   }
-  cilqr::vandermonde_lstsq(s, rows, cols, coeffs);
+  cilqr::vandermonde_lstsq<0>(s, rows, cols, coeffs);
 }
 
 }  // namespace

@@ -27,11 +27,28 @@
 
 namespace cilqr {
 
-template <class Store>
+// Row loops.  RM = 0: plain loops (host).  RM > 0 (device; the store has room for RM rows): fully unrolled over RM rows with
+// the body told whether its row is in [from, rows) — loads are then unconditional and independent of one another, so a lane
+// has RM of them in flight instead of waiting out one LDS round trip per row.  Sums run in the same order either way.
+template <int RM, class Body>
+CILQR_HD void for_rows(int from, int rows, Body&& body) {
+  if constexpr (RM > 0) {
+#pragma unroll
+    for (int i = 0; i < RM; ++i) body(i, i >= from && i < rows);
+  } else {
+    for (int i = from; i < rows; ++i) body(i, true);
+  }
+}
+
+template <int RM, class Store>
 CILQR_HD double tail_sq_norm(Store& s, int rows, int col, int from) {
 #pragma clang fp contract(off)
   double acc = 0.0;
-  for (int i = from; i < rows; ++i) acc += s.m(i, col) * s.m(i, col);
+  for_rows<RM>(from, rows, [&](int i, bool on) {
+#pragma clang fp contract(off)
+    const double v = s.m(i, col);
+    if (on) acc += v * v;
+  });
   return acc;
 }
 
@@ -43,7 +60,7 @@ CILQR_HD void swap_values(T& a, T& b) {
 }
 
 // Least squares min |V c - y|; coeffs[0..cols) receives the solution.
-template <class Store>
+template <int RM = 0, class Store>
 CILQR_HD void vandermonde_lstsq(Store& s, int rows, int cols, double* coeffs) {
 #pragma clang fp contract(off)
   const int diag = rows < cols ? rows : cols;
@@ -53,7 +70,7 @@ CILQR_HD void vandermonde_lstsq(Store& s, int rows, int cols, double* coeffs) {
   }
   double max_norm = 0.0;
   for (int j = 0; j < cols; ++j) {
-    s.col_norm(j) = tail_sq_norm(s, rows, j, 0);
+    s.col_norm(j) = tail_sq_norm<RM>(s, rows, j, 0);
     if (j == 0 || s.col_norm(j) > max_norm) max_norm = s.col_norm(j);
   }
   const double cut = max_norm * (DBL_EPSILON * DBL_EPSILON) / (double)rows;
@@ -62,26 +79,33 @@ CILQR_HD void vandermonde_lstsq(Store& s, int rows, int cols, double* coeffs) {
     int pivot = k;
     for (int j = k + 1; j < cols; ++j)
       if (s.col_norm(j) > s.col_norm(pivot)) pivot = j;
-    const double exact = tail_sq_norm(s, rows, pivot, k);
+    const double exact = tail_sq_norm<RM>(s, rows, pivot, k);
     s.col_norm(pivot) = exact;
     if (rank == diag && exact < cut * (double)(rows - k)) rank = k;
     s.swap_with(k) = pivot;
     if (pivot != k) {
-      for (int i = 0; i < rows; ++i) swap_values(s.m(i, k), s.m(i, pivot));
+      for_rows<RM>(0, rows, [&](int i, bool on) {
+        const double a = s.m(i, k), b = s.m(i, pivot);
+        if (on) { s.m(i, k) = b; s.m(i, pivot) = a; }
+      });
       swap_values(s.col_norm(k), s.col_norm(pivot));
     }
     // Householder vector for column k (stored below the diagonal, unit leading entry implied)
-    const double below = tail_sq_norm(s, rows, k, k + 1);
+    const double below = tail_sq_norm<RM>(s, rows, k, k + 1);
     const double head = s.m(k, k);
     double beta;
     if (below == 0.0) {
       s.tau(k) = 0.0;
       beta = head;
-      for (int i = k + 1; i < rows; ++i) s.m(i, k) = 0.0;
+      for_rows<RM>(k + 1, rows, [&](int i, bool on) { if (on) s.m(i, k) = 0.0; });
     } else {
       beta = sqrt(head * head + below);
       if (head >= 0.0) beta = -beta;
-      for (int i = k + 1; i < rows; ++i) s.m(i, k) = s.m(i, k) / (head - beta);
+      const double den = head - beta;
+      for_rows<RM>(k + 1, rows, [&](int i, bool on) {
+        const double v = s.m(i, k);
+        if (on) s.m(i, k) = v / den;
+      });
       s.tau(k) = (beta - head) / beta;
     }
     s.m(k, k) = beta;
@@ -92,10 +116,18 @@ CILQR_HD void vandermonde_lstsq(Store& s, int rows, int cols, double* coeffs) {
         s.m(k, j) *= (1 - tk);
       } else {
         double dot = 0.0;
-        for (int i = k + 1; i < rows; ++i) dot += s.m(i, k) * s.m(i, j);
+        for_rows<RM>(k + 1, rows, [&](int i, bool on) {
+#pragma clang fp contract(off)
+          const double a = s.m(i, k), b = s.m(i, j);
+          if (on) dot += a * b;
+        });
         dot += s.m(k, j);
         s.m(k, j) -= tk * dot;
-        for (int i = k + 1; i < rows; ++i) s.m(i, j) -= tk * s.m(i, k) * dot;
+        for_rows<RM>(k + 1, rows, [&](int i, bool on) {
+#pragma clang fp contract(off)
+          const double a = s.m(i, k), b = s.m(i, j);
+          if (on) s.m(i, j) = b - tk * a * dot;
+        });
       }
       s.col_norm(j) -= s.m(k, j) * s.m(k, j);
     }
@@ -112,10 +144,18 @@ CILQR_HD void vandermonde_lstsq(Store& s, int rows, int cols, double* coeffs) {
       continue;
     }
     double dot = 0.0;
-    for (int i = k + 1; i < rows; ++i) dot += s.m(i, k) * s.c(i);
+    for_rows<RM>(k + 1, rows, [&](int i, bool on) {
+#pragma clang fp contract(off)
+      const double a = s.m(i, k), b = s.c(i);
+      if (on) dot += a * b;
+    });
     dot += s.c(k);
     s.c(k) -= tk * dot;
-    for (int i = k + 1; i < rows; ++i) s.c(i) -= tk * s.m(i, k) * dot;
+    for_rows<RM>(k + 1, rows, [&](int i, bool on) {
+#pragma clang fp contract(off)
+      const double a = s.m(i, k), b = s.c(i);
+      if (on) s.c(i) = b - tk * a * dot;
+    });
   }
   for (int i = rank - 1; i >= 0; --i) {
     double acc = s.c(i);
