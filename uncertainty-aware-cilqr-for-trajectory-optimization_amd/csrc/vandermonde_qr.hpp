@@ -111,25 +111,44 @@ CILQR_HD void vandermonde_lstsq(Store& s, int rows, int cols, double* coeffs) {
     s.m(k, k) = beta;
     const double tk = s.tau(k);
     // reflect the trailing columns
-    for (int j = k + 1; j < cols; ++j) {
-      if (rows - k == 1) {
-        s.m(k, j) *= (1 - tk);
-      } else {
-        double dot = 0.0;
-        for_rows<RM>(k + 1, rows, [&](int i, bool on) {
-#pragma clang fp contract(off)
-          const double a = s.m(i, k), b = s.m(i, j);
-          if (on) dot += a * b;
-        });
-        dot += s.m(k, j);
-        s.m(k, j) -= tk * dot;
-        for_rows<RM>(k + 1, rows, [&](int i, bool on) {
-#pragma clang fp contract(off)
-          const double a = s.m(i, k), b = s.m(i, j);
-          if (on) s.m(i, j) = b - tk * a * dot;
-        });
+    if constexpr (RM > 0) {
+      // device: the Householder vector is read once per k and each trailing column once per (k, j), RM independent loads at
+      // a time, into registers; the arithmetic and its order are those of the plain loops below
+      double vk[RM];
+#pragma unroll
+      for (int i = 0; i < RM; ++i) vk[i] = s.m(i, k);
+      for (int j = k + 1; j < cols; ++j) {
+        if (rows - k == 1) {
+          s.m(k, j) *= (1 - tk);
+        } else {
+          double bj[RM];
+#pragma unroll
+          for (int i = 0; i < RM; ++i) bj[i] = s.m(i, j);
+          double dot = 0.0;
+#pragma unroll
+          for (int i = 0; i < RM; ++i)
+            if (i >= k + 1 && i < rows) dot += vk[i] * bj[i];
+          dot += s.m(k, j);
+          s.m(k, j) -= tk * dot;
+#pragma unroll
+          for (int i = 0; i < RM; ++i)
+            if (i >= k + 1 && i < rows) s.m(i, j) = bj[i] - tk * vk[i] * dot;
+        }
+        s.col_norm(j) -= s.m(k, j) * s.m(k, j);
       }
-      s.col_norm(j) -= s.m(k, j) * s.m(k, j);
+    } else {
+      for (int j = k + 1; j < cols; ++j) {
+        if (rows - k == 1) {
+          s.m(k, j) *= (1 - tk);
+        } else {
+          double dot = 0.0;
+          for (int i = k + 1; i < rows; ++i) dot += s.m(i, k) * s.m(i, j);
+          dot += s.m(k, j);
+          s.m(k, j) -= tk * dot;
+          for (int i = k + 1; i < rows; ++i) s.m(i, j) -= tk * s.m(i, k) * dot;
+        }
+        s.col_norm(j) -= s.m(k, j) * s.m(k, j);
+      }
     }
   }
   for (int j = 0; j < cols; ++j) s.order(j) = j;
@@ -143,19 +162,29 @@ CILQR_HD void vandermonde_lstsq(Store& s, int rows, int cols, double* coeffs) {
       s.c(k) *= (1 - tk);
       continue;
     }
-    double dot = 0.0;
-    for_rows<RM>(k + 1, rows, [&](int i, bool on) {
-#pragma clang fp contract(off)
-      const double a = s.m(i, k), b = s.c(i);
-      if (on) dot += a * b;
-    });
-    dot += s.c(k);
-    s.c(k) -= tk * dot;
-    for_rows<RM>(k + 1, rows, [&](int i, bool on) {
-#pragma clang fp contract(off)
-      const double a = s.m(i, k), b = s.c(i);
-      if (on) s.c(i) = b - tk * a * dot;
-    });
+    if constexpr (RM > 0) {
+      double vk[RM], cv[RM];
+#pragma unroll
+      for (int i = 0; i < RM; ++i) {
+        vk[i] = s.m(i, k);
+        cv[i] = s.c(i);
+      }
+      double dot = 0.0;
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+        if (i >= k + 1 && i < rows) dot += vk[i] * cv[i];
+      dot += s.c(k);
+      s.c(k) -= tk * dot;
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+        if (i >= k + 1 && i < rows) s.c(i) = cv[i] - tk * vk[i] * dot;
+    } else {
+      double dot = 0.0;
+      for (int i = k + 1; i < rows; ++i) dot += s.m(i, k) * s.c(i);
+      dot += s.c(k);
+      s.c(k) -= tk * dot;
+      for (int i = k + 1; i < rows; ++i) s.c(i) -= tk * s.m(i, k) * dot;
+    }
   }
   for (int i = rank - 1; i >= 0; --i) {
     double acc = s.c(i);
