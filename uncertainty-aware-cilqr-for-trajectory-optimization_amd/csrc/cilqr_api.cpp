@@ -52,6 +52,8 @@ struct cilqr_handle {
   float *d_src, *d_dst, *d_bbox;
   size_t src_cap, dst_cap, bbox_cap;
   unsigned long long* d_oob;
+  float* d_occ_steps;  // 8 x 128 floats: step tables of the layer -> occupancy conversion (rebuilt per call on the call's stream)
+  unsigned occ_slot;
   unsigned long long* diag;  // caller-owned device buffer or null
 };
 
@@ -185,6 +187,7 @@ int cilqr_create(const cilqr_params* p, int max_batch, int max_horizon, int max_
   if (err == hipSuccess) err = dmalloc(&h->d_redo, B);
   if (err == hipSuccess) err = dmalloc(&h->d_pair, (size_t)2);
   if (err == hipSuccess) err = dmalloc(&h->d_oob, (size_t)1);
+  if (err == hipSuccess) err = dmalloc(&h->d_occ_steps, (size_t)8 * 128);
   if (err != hipSuccess) {
     int rc = fail(CILQR_ERR_HIP, "cilqr_create: device allocation failed: %s", hipGetErrorString(err));
     cilqr_destroy(h);
@@ -199,7 +202,7 @@ int cilqr_destroy(cilqr_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->d_x0, h->d_U, h->d_poly, h->d_xplan, h->d_obs_pose, h->d_obs_dim, h->d_obs_w, h->d_samp_off, h->d_X, h->d_J,
-                  h->d_iters, h->d_status, h->d_obs_tab, h->d_ws, h->d_redo, h->d_pair, h->d_src, h->d_dst, h->d_bbox, h->d_oob};
+                  h->d_iters, h->d_status, h->d_obs_tab, h->d_ws, h->d_redo, h->d_pair, h->d_src, h->d_dst, h->d_bbox, h->d_oob, h->d_occ_steps};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -501,7 +504,9 @@ int cilqr_layer_to_occupancy_device(cilqr_handle* h, void* stream, const float* 
   if (!h || n_cells < 0 || (n_cells > 0 && (!occ || !layer))) return fail(CILQR_ERR_ARG, "cilqr_layer_to_occupancy: bad argument");
   if (n_cells == 0) return CILQR_OK;
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(cilqr::launch_layer_to_occ(layer, occ, (long)n_cells, data_min, data_max, (hipStream_t)stream));
+  // the step table is rebuilt on the call's stream; eight slots in rotation keep calls in flight on other streams apart
+  float* steps = h->d_occ_steps + 128 * (h->occ_slot++ & 7);
+  HIP_TRY(cilqr::launch_layer_to_occ(layer, occ, (long)n_cells, data_min, data_max, steps, (hipStream_t)stream));
   return CILQR_OK;
 }
 

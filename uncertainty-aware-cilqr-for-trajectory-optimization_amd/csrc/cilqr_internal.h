@@ -102,7 +102,9 @@ struct BlurArgs {
 hipError_t launch_blur(const BlurArgs& a, hipStream_t stream);
 // OccupancyGrid <-> layer (costmap_occupancy.hip)
 hipError_t launch_occ_to_layer(const int8_t* occ, float* layer, long n, hipStream_t stream);
-hipError_t launch_layer_to_occ(const float* layer, int8_t* occ, long n, float data_min, float data_max, hipStream_t stream);
+// steps_ws: 102 floats of device workspace for the step table of large conversions (null: always the per-cell division)
+hipError_t launch_layer_to_occ(const float* layer, int8_t* occ, long n, float data_min, float data_max, float* steps_ws,
+                               hipStream_t stream);
 hipError_t launch_blur_ellipse(int n, const double* abc, double* out, hipStream_t stream);
 
 }  // namespace cilqr
