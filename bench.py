@@ -7,7 +7,7 @@
 
 A step = one pass of the hot path over one batch: `cilqr_solve_batch_device` on BASELINE config 2 (B=1024 seeded synthetic
 scenes, N=50, M=4 obstacles, fp64) with every input already resident in HBM, followed by the min-cost selection
-(`cilqr_argmin_device`; with N > 1 ranks, one RCCL all-gather of the 16-byte (J, index) pairs — SURVEY §8e).  Each rank
+(`cilqr_argmin_device`; with N > 1 ranks, one RCCL all-gather of 24 bytes per rank — the (J, index) pair and the rank's index offset — SURVEY §8e).  Each rank
 owns its own shard of B scenes (weak scaling, no data-path collective).  The warm-start U is restored from a device copy
 inside the timed region, because the solve overwrites it.
 Prints ONE JSON line on rank 0.

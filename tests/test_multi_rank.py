@@ -1,5 +1,5 @@
 """N > 1 path on CPU: world_size-2 gloo process group.  The batch shards by scene with no data-path collective; the one
-exchange step is an all-gather of the per-rank 16-byte (J_min, index) pairs (cilqr_amd/dist.py)."""
+exchange step is an all-gather of 24 bytes per rank: the (J_min, local index) pair and the rank's index offset (cilqr_amd/dist.py)."""
 import os
 import socket
 
