@@ -107,7 +107,7 @@ def bench_warp(args, rank, local_rank, world, dist, dev):
                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC_BYTES.get(("warp", S)),
                             "traffic_source": "profiles/r01_wide_rows_summary.md (FETCH_SIZE x2 + WRITE_SIZE)" if S == 1024 else None,
                             "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch}}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a rank-0, N=1 measurement
             from oracle import oracle as O
             O.build(ref=False)
             threads = O.max_threads()
@@ -184,7 +184,7 @@ def bench_blur(args, rank, local_rank, world, dist, dev):
                              "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms,
                              "algorithmic_bytes_per_launch": bytes_launch,
                              "note": "fp64-VALU-bound: ~20-400 tested cells and ~20-80 exp() per output cell"}}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a rank-0, N=1 measurement
             from oracle import oracle as O
             O.build(ref=False)
             threads = O.max_threads()
@@ -276,7 +276,7 @@ def bench_occ(args, rank, local_rank, world, dist, dev):
         out["occ_to_layer_kernel"] = {"kernel_ms": to_layer_ms, "achieved": bytes_launch / (to_layer_ms * 1e-3) / 1e9, "unit": "GB/s",
                                       "frac": bytes_launch / (to_layer_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         out["round_trip_exact"] = bool(torch.equal(back, occ))
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a rank-0, N=1 measurement
             from oracle import oracle as O
             O.build(ref=False)
             ns = min(n, 1 << 26)
@@ -343,7 +343,7 @@ def bench_frame(args, rank, local_rank, world, dist, dev):
                     {"bound": "hbm", "kernel": "warp_kernel + blur_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch,
                      "note": "both launches of one frame inside the event pair; the blur is fp64-VALU-bound, see DESIGN.md §4.5"})
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a rank-0, N=1 measurement
             from oracle import oracle as O
             O.build(ref=False)
             threads = O.max_threads()
@@ -398,7 +398,7 @@ def bench_plan(args, rank, local_rank, world, dist, dev):
                     {"bound": "hbm", "kernel": "local_plan_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch,
                      "note": "serial-chain bound: one lane per fit, sums kept in the host pre-step's order"})
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a rank-0, N=1 measurement
             from oracle import oracle as O
             O.build(ref=False)
             po = O.default_params(50)
@@ -564,9 +564,9 @@ def main():
             "min_cost": {"J": best[0], "global_index": best[1]},
         }
         # SURVEY §8(d) also asks for the host-buffer entry point (H2D + kernel + D2H); reported, never `value`
-        reps = 3 if M <= 16 else 1
+        reps = (3 if M <= 16 else 1) if world == 1 else 0
         hb = None
-        for _ in range(reps + 1):  # first call untimed
+        for _ in range(reps + 1 if reps else 0):  # first call untimed
             th = time.perf_counter()
             if sampled:
                 solver.solve_batch_sampled(N, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["nom_pose"], sc["nom_dim"], sc["offsets"],
@@ -575,9 +575,10 @@ def main():
                 solver.solve_batch(N, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"], sc["obs_weight"])
             th = time.perf_counter() - th
             hb = th if hb is None else min(hb, th)
-        out["host_buffer_api"] = {"value": B / hb, "unit": "solves/s", "ms_per_batch": 1e3 * hb,
-                                  "note": "cilqr_solve_batch from pageable host memory, PCIe copies included (best of %d)" % reps}
-        if not args.no_cpu_baseline:
+        if hb is not None:
+            out["host_buffer_api"] = {"value": B / hb, "unit": "solves/s", "ms_per_batch": 1e3 * hb,
+                                      "note": "cilqr_solve_batch from pageable host memory, PCIe copies included (best of %d)" % reps}
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a rank-0, N=1 measurement
             from oracle import oracle as O
             O.build(ref=False)
             threads = O.max_threads()

@@ -21,10 +21,13 @@ using namespace dev;
 
 namespace {
 
-// Per-wavefront workspace block, in rows of S doubles (one column per solve of the wavefront), FIELD-major:
-// row(field f of an array, step t) = array base + f*(steps of that array) + t.  In phase L the 64 lanes (step t = g + k·G,
-// solve grp) of one load instruction then cover G·S = 64 consecutive doubles (512 B, fully coalesced); in the serial
-// phases the lanes of a group share a row and the S groups read S consecutive doubles.
+// Per-wavefront workspace block, in rows of S doubles (one column per solve of the wavefront), STEP-major:
+// row(field f of an array, step t) = array base + t*(fields of that array) + f.  The serial phases R and F, which take most
+// of a solve, then address a step's 16 + 10 operands with ONE base register and immediate offsets f·S·8 (field-major rows
+// needed a 64-bit address computation per operand: R was 1 712 ticks per step against 930 in the LDS family, and requesting
+// operands further ahead did not help — it was issue, not latency).  Phase L pays with strided rows: the lanes of a load
+// (G steps × S solves) touch G separate S·8-byte segments instead of 512 contiguous bytes, 26 such accesses per step
+// against thousands of arithmetic instructions.
 struct WsLayout {
   int N, M;
   __device__ __host__ int xa() const { return 0; }
@@ -63,10 +66,10 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
   // column `grp` of this wavefront's block: element (row r) at ws[r * S]
   double* ws = ws_base + (size_t)blockIdx.x * L.rows() * S + grp;
   double* tab = a.obs_tab + (size_t)blockIdx.x * ((size_t)M * N * TABF) * S + grp;  // rows ((m*6 + f)*N + t)
-#define XF(base, t, f) ws[(size_t)((base) + (f) * (N + 1) + (t)) * S] /* state arrays: 6 fields x (N+1) steps */
-#define UF(base, t, f) ws[(size_t)((base) + (f) * N + (t)) * S]       /* control arrays: 2 fields x N steps */
-#define RF(t, f) ws[(size_t)(L.rec() + (f) * N + (t)) * S]            /* linearisation: 16 fields x N steps */
-#define KF(t, f) ws[(size_t)(L.kk() + (f) * N + (t)) * S]             /* gains: 10 fields x N steps */
+#define XF(base, t, f) ws[(size_t)((base) + (t) * XR + (f)) * S]  /* state arrays: (N+1) steps x 6 fields */
+#define UF(base, t, f) ws[(size_t)((base) + (t) * 2 + (f)) * S]   /* control arrays: N steps x 2 fields */
+#define RF(t, f) ws[(size_t)(L.rec() + (t) * REC + (f)) * S]      /* linearisation: N steps x 16 fields */
+#define KF(t, f) ws[(size_t)(L.kk() + (t) * KR + (f)) * S]        /* gains: N steps x 10 fields */
 
   // ---- prologue -------------------------------------------------------------------------------------------
   double pc[CILQR_POLY_COEFFS];
@@ -110,8 +113,8 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
 
   auto store_state = [&](int base, int t, const State& s) {
     if (g == 0) {
-      XF(base, t, 0) = s.x; XF(base, t, 1) = s.y; XF(base, t, 2) = s.v;
-      XF(base, t, 3) = s.th; XF(base, t, 4) = s.c; XF(base, t, 5) = s.s;
+      double* xr = &XF(base, t, 0);
+      xr[0] = s.x; xr[S] = s.y; xr[2 * S] = s.v; xr[3 * S] = s.th; xr[4 * S] = s.c; xr[5 * S] = s.s;
     }
   };
 
@@ -172,9 +175,10 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
       Rec c;
       Jpart += lin_step(kp, px, py, XF(xc, t, 2), XF(xc, t, 4), XF(xc, t, 5), UF(uc, t, 0), UF(uc, t, 1), XF(xc, t + 1, 2),
                         XF(xc, t + 1, 4), XF(xc, t + 1, 5), cx, cy, M, obs, c);
-      RF(t, 0) = c.lx0; RF(t, 1) = c.lx1; RF(t, 2) = c.lx2; RF(t, 3) = c.l00; RF(t, 4) = c.l01; RF(t, 5) = c.l11;
-      RF(t, 6) = c.lu0; RF(t, 7) = c.lu1; RF(t, 8) = c.luu0; RF(t, 9) = c.luu1;
-      RF(t, 10) = c.al; RF(t, 11) = c.be; RF(t, 12) = c.ga; RF(t, 13) = c.de; RF(t, 14) = c.p; RF(t, 15) = c.q;
+      double* r = &RF(t, 0);
+      r[0] = c.lx0; r[S] = c.lx1; r[2 * S] = c.lx2; r[3 * S] = c.l00; r[4 * S] = c.l01; r[5 * S] = c.l11;
+      r[6 * S] = c.lu0; r[7 * S] = c.lu1; r[8 * S] = c.luu0; r[9 * S] = c.luu1;
+      r[10 * S] = c.al; r[11 * S] = c.be; r[12 * S] = c.ga; r[13 * S] = c.de; r[14 * S] = c.p; r[15 * S] = c.q;
     }
     J_new = group_sum<G>(Jpart);
     j_valid = true;
@@ -196,10 +200,12 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
     // ---- phase R: backward recursion (all lanes of the group compute the same values)
     bool r_ok = true;
     {
+      // one 64-bit base per step, the 16 operands at immediate offsets f·S doubles from it
       auto load_rec = [&](Rec& o, int j) {
-        o.lx0 = RF(j, 0); o.lx1 = RF(j, 1); o.lx2 = RF(j, 2); o.l00 = RF(j, 3); o.l01 = RF(j, 4); o.l11 = RF(j, 5);
-        o.lu0 = RF(j, 6); o.lu1 = RF(j, 7); o.luu0 = RF(j, 8); o.luu1 = RF(j, 9);
-        o.al = RF(j, 10); o.be = RF(j, 11); o.ga = RF(j, 12); o.de = RF(j, 13); o.p = RF(j, 14); o.q = RF(j, 15);
+        const double* r = &RF(j, 0);
+        o.lx0 = r[0]; o.lx1 = r[S]; o.lx2 = r[2 * S]; o.l00 = r[3 * S]; o.l01 = r[4 * S]; o.l11 = r[5 * S];
+        o.lu0 = r[6 * S]; o.lu1 = r[7 * S]; o.luu0 = r[8 * S]; o.luu1 = r[9 * S];
+        o.al = r[10 * S]; o.be = r[11 * S]; o.ga = r[12 * S]; o.de = r[13 * S]; o.p = r[14 * S]; o.q = r[15 * S];
       };
       Rec ra, rb;
       load_rec(ra, N - 1);
@@ -211,8 +217,9 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
         riccati_step<!GENERAL>(c, V, dt, two_wvel, lamb, gn, ok);
         r_ok = r_ok && ok;
         if (g == 0 && (!GENERAL || ok)) {
+          double* kp_ = &KF(j, 0);
 #pragma unroll
-          for (int i = 0; i < KR; ++i) KF(j, i) = gn.g[i];
+          for (int i = 0; i < KR; ++i) kp_[i * S] = gn.g[i];
         }
       };
       int j = N - 1;
@@ -238,10 +245,13 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
       s.x = XF(xc, 0, 0); s.y = XF(xc, 0, 1); s.v = XF(xc, 0, 2); s.th = XF(xc, 0, 3); s.c = XF(xc, 0, 4); s.s = XF(xc, 0, 5);
       store_state(xn, 0, s);
       auto load_fwd = [&](FwdIn& o, int i) {
-        o.x = XF(xc, i, 0); o.y = XF(xc, i, 1); o.v = XF(xc, i, 2); o.th = XF(xc, i, 3);
-        o.u0 = UF(uc, i, 0); o.u1 = UF(uc, i, 1);
+        const double* xr = &XF(xc, i, 0);
+        const double* ur = &UF(uc, i, 0);
+        const double* kr = &KF(i, 0);
+        o.x = xr[0]; o.y = xr[S]; o.v = xr[2 * S]; o.th = xr[3 * S];
+        o.u0 = ur[0]; o.u1 = ur[S];
 #pragma unroll
-        for (int k = 0; k < KR; ++k) o.g[k] = KF(i, k);
+        for (int k = 0; k < KR; ++k) o.g[k] = kr[k * S];
       };
       if (GENERAL) {
         for (int i = 0; i < N; ++i) {
@@ -251,7 +261,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
           const double u0 = fma(c.g[5], d3, fma(c.g[4], d2, fma(c.g[3], d1, fma(c.g[2], d0, c.u0 + c.g[0]))));
           const double u1 = fma(c.g[9], d3, fma(c.g[8], d2, fma(c.g[7], d1, fma(c.g[6], d0, c.u1 + c.g[1]))));
           s = dyn_step(kp, s, u0, u1);
-          if (g == 0) { UF(un, i, 0) = u0; UF(un, i, 1) = u1; }
+          if (g == 0) { double* ur = &UF(un, i, 0); ur[0] = u0; ur[S] = u1; }
           store_state(xn, i + 1, s);
         }
       } else {
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
         auto step = [&](const FwdIn& c, int i) {
           double u0, u1;
           forward_step(k, c, s, max_th, u0, u1);
-          if (g == 0) { UF(un, i, 0) = u0; UF(un, i, 1) = u1; }
+          if (g == 0) { double* ur = &UF(un, i, 0); ur[0] = u0; ur[S] = u1; }
           store_state(xn, i + 1, s);
         };
         int i = 0;
