@@ -52,8 +52,55 @@ __device__ __forceinline__ void mem_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// Staging of the serial phases' operands (fast kernel).  Loads and stores of a wavefront retire through one in-order counter
+// on this hardware, so operands requested one step ahead from global memory queue behind the previous step's stores and
+// every step waits out a store round trip (R measured 1 580 ticks per step against 930 for the LDS-resident family).  Here
+// the operands of a whole chunk of steps are copied global → LDS by the asynchronous direct-to-LDS load (no registers), one
+// chunk ahead; the step loops read LDS and only store to global; the one vmcnt wait per chunk finds the copy long finished.
+extern __shared__ __attribute__((aligned(16))) double cilqr_groups_stage[];
+__device__ __forceinline__ double* stage_base() { return cilqr_groups_stage; }
+constexpr int STAGE_ROWS = XR + 2 + KR;  // per step: the larger of R's 16 record rows and F's 6 + 2 + 10 state/control/gain rows
+// n_doubles (even) contiguous doubles from src (global, wave-uniform) to dst (LDS, wave-uniform): 16 bytes per lane and
+// instruction, 1 KiB per instruction.  The copy is a job of the whole wavefront, but the solves of a wavefront finish at
+// different iterations and their lanes are switched off from then on — so each piece is issued with EXEC forced to the lanes
+// it needs (and restored), the lane's byte offset formed inside from v_mbcnt, the LDS base in M0 (tools/ubench_lds_direct.hip
+// checks this sequence from divergent code).  The compiler does not know these loads: stage_wait() is their only wait.
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+  return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ void stage_copy(const double* src, double* dst, int n_doubles) {
+  // every quantity here is the same in all active lanes; readfirstlane tells the compiler so (the loop counters they come from
+  // live in vector registers because the iteration loop is divergent)
+  const int bytes = __builtin_amdgcn_readfirstlane(n_doubles * 8);
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_groupstaticsize() + (unsigned)((dst - stage_base()) * sizeof(double)));
+  const unsigned long long src0 = uniform64(reinterpret_cast<unsigned long long>(src));
+  for (int off = 0; off < bytes; off += WAVE * 16) {
+    const int lanes = (bytes - off) / 16;
+    const unsigned long long mask = uniform64(lanes >= WAVE ? ~0ull : ((1ull << lanes) - 1));
+    const unsigned long long piece = uniform64(src0 + (unsigned long long)off);
+    const unsigned lds_byte = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)off));
+    unsigned long long save;
+    unsigned vtmp;
+    asm volatile(
+        "s_mov_b64 %0, exec\n\t"
+        "s_mov_b64 exec, %3\n\t"
+        "v_mbcnt_lo_u32_b32 %1, -1, 0\n\t"
+        "v_mbcnt_hi_u32_b32 %1, -1, %1\n\t"
+        "v_lshlrev_b32 %1, 4, %1\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b64 exec, %0"
+        : "=&s"(save), "=&v"(vtmp)
+        : "s"(piece), "s"(mask), "s"(lds_byte)
+        : "memory", "m0");
+  }
+}
+__device__ __forceinline__ void stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <int G, bool GENERAL>
-__global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, double* ws_base) {
+__global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, double* ws_base, int chunk) {
+  double* stage = stage_base();  // fast kernel: 2 staging buffers of chunk·STAGE_ROWS·S doubles (dynamic LDS)
   constexpr int S = WAVE / G;
   const int lane = threadIdx.x, grp = lane / G, g = lane % G;
   const int b = blockIdx.x * S + grp;
@@ -208,9 +255,11 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
         o.al = r[10 * S]; o.be = r[11 * S]; o.ga = r[12 * S]; o.de = r[13 * S]; o.p = r[14 * S]; o.q = r[15 * S];
       };
       Rec ra, rb;
-      load_rec(ra, N - 1);
       Value V;
-      value_terminal(V, ra, two_wvel);
+      if (GENERAL) {
+        load_rec(ra, N - 1);
+        value_terminal(V, ra, two_wvel);
+      }
       Gains gn;
       bool ok;
       auto step = [&](const Rec& c, int j) {
@@ -222,14 +271,49 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
           for (int i = 0; i < KR; ++i) kp_[i * S] = gn.g[i];
         }
       };
-      int j = N - 1;
-      for (; j >= 1 && (!GENERAL || r_ok); j -= 2) {
-        load_rec(rb, j - 1);
-        step(ra, j);
-        load_rec(ra, j >= 2 ? j - 2 : 0);
-        if (!GENERAL || r_ok) step(rb, j - 1);
+      if (GENERAL) {
+        int j = N - 1;
+        for (; j >= 1 && r_ok; j -= 2) {
+          load_rec(rb, j - 1);
+          step(ra, j);
+          load_rec(ra, j >= 2 ? j - 2 : 0);
+          if (r_ok) step(rb, j - 1);
+        }
+        if (j == 0 && r_ok) step(ra, 0);
+      } else {
+        // chunks of `chunk` steps, newest first; chunk c+1 is copied while chunk c is computed
+        const double* wave_ws = ws_base + (size_t)blockIdx.x * L.rows() * S;  // this wavefront's block, column 0
+        const int buf_doubles = chunk * STAGE_ROWS * S;
+        auto rows_of = [&](int lo) { return wave_ws + (size_t)(L.rec() + lo * REC) * S; };
+        auto lds_rec = [&](Rec& o, const double* base, int t_rel) {
+          const double* r = base + (size_t)t_rel * REC * S + grp;
+          o.lx0 = r[0]; o.lx1 = r[S]; o.lx2 = r[2 * S]; o.l00 = r[3 * S]; o.l01 = r[4 * S]; o.l11 = r[5 * S];
+          o.lu0 = r[6 * S]; o.lu1 = r[7 * S]; o.luu0 = r[8 * S]; o.luu1 = r[9 * S];
+          o.al = r[10 * S]; o.be = r[11 * S]; o.ga = r[12 * S]; o.de = r[13 * S]; o.p = r[14 * S]; o.q = r[15 * S];
+        };
+        int hi = N - 1, lo = hi - chunk + 1 < 0 ? 0 : hi - chunk + 1, buf = 0;
+        stage_copy(rows_of(lo), stage, (hi - lo + 1) * REC * S);
+        stage_wait();
+        while (hi >= 0) {
+          const int nhi = lo - 1, nlo = nhi - chunk + 1 < 0 ? 0 : nhi - chunk + 1;
+          if (nhi >= 0) stage_copy(rows_of(nlo), stage + (buf ^ 1) * buf_doubles, (nhi - nlo + 1) * REC * S);
+          const double* cur = stage + buf * buf_doubles;
+          int j = hi;
+          lds_rec(ra, cur, j - lo);
+          if (j == N - 1) value_terminal(V, ra, two_wvel);
+          for (; j >= lo + 1; j -= 2) {  // two steps per trip, the next record's LDS reads under this step's arithmetic
+            lds_rec(rb, cur, j - 1 - lo);
+            step(ra, j);
+            lds_rec(ra, cur, j - 2 >= lo ? j - 2 - lo : 0);
+            step(rb, j - 1);
+          }
+          if (j == lo) step(ra, lo);
+          stage_wait();  // the next chunk has landed (and this chunk's gain stores have been accepted)
+          hi = nhi;
+          lo = nlo;
+          buf ^= 1;
+        }
       }
-      if (j == 0 && (!GENERAL || r_ok)) step(ra, 0);
     }
     if (!r_ok) {
       if (GENERAL) { status = CILQR_EXIT_NUMERIC; break; }
@@ -269,21 +353,51 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
         make_fwd_const(k, kp);
         double max_th = fabs(s.th);
         FwdIn fa, fb;
-        load_fwd(fa, 0);
         auto step = [&](const FwdIn& c, int i) {
           double u0, u1;
           forward_step(k, c, s, max_th, u0, u1);
           if (g == 0) { double* ur = &UF(un, i, 0); ur[0] = u0; ur[S] = u1; }
           store_state(xn, i + 1, s);
         };
-        int i = 0;
-        for (; i + 1 < N; i += 2) {
-          load_fwd(fb, i + 1);
-          step(fa, i);
-          load_fwd(fa, i + 2 < N ? i + 2 : i + 1);
-          step(fb, i + 1);
+        // chunks of `chunk` steps, oldest first: X rows, U rows and gain rows of a chunk side by side in a staging buffer
+        const double* wave_ws = ws_base + (size_t)blockIdx.x * L.rows() * S;
+        const int buf_doubles = chunk * STAGE_ROWS * S;
+        auto copy_chunk = [&](int lo, int hi, double* dst) {
+          const int n = hi - lo + 1;
+          stage_copy(wave_ws + (size_t)(xc + lo * XR) * S, dst, n * XR * S);
+          stage_copy(wave_ws + (size_t)(uc + lo * 2) * S, dst + chunk * XR * S, n * 2 * S);
+          stage_copy(wave_ws + (size_t)(L.kk() + lo * KR) * S, dst + chunk * (XR + 2) * S, n * KR * S);
+        };
+        auto lds_fwd = [&](FwdIn& o, const double* base, int t_rel) {
+          const double* xr = base + (size_t)t_rel * XR * S + grp;
+          const double* ur = base + (size_t)(chunk * XR + t_rel * 2) * S + grp;
+          const double* kr = base + (size_t)(chunk * (XR + 2) + t_rel * KR) * S + grp;
+          o.x = xr[0]; o.y = xr[S]; o.v = xr[2 * S]; o.th = xr[3 * S];
+          o.u0 = ur[0]; o.u1 = ur[S];
+#pragma unroll
+          for (int q = 0; q < KR; ++q) o.g[q] = kr[q * S];
+        };
+        int lo = 0, hi = chunk - 1 < N - 1 ? chunk - 1 : N - 1, buf = 0;
+        copy_chunk(lo, hi, stage);
+        stage_wait();
+        while (lo < N) {
+          const int nlo = hi + 1, nhi = nlo + chunk - 1 < N - 1 ? nlo + chunk - 1 : N - 1;
+          if (nlo < N) copy_chunk(nlo, nhi, stage + (buf ^ 1) * buf_doubles);
+          const double* cur = stage + buf * buf_doubles;
+          int i = lo;
+          lds_fwd(fa, cur, 0);
+          for (; i + 1 <= hi; i += 2) {
+            lds_fwd(fb, cur, i + 1 - lo);
+            step(fa, i);
+            lds_fwd(fa, cur, i + 2 <= hi ? i + 2 - lo : 0);
+            step(fb, i + 1);
+          }
+          if (i == hi) step(fa, hi);
+          stage_wait();
+          lo = nlo;
+          hi = nhi;
+          buf ^= 1;
         }
-        if (i < N) step(fa, i);
         if (!(max_th < 1.0e6)) { handover = true; break; }
       }
     }
@@ -346,12 +460,23 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
 #undef KF
 }
 
+// Steps per staging chunk: two buffers within 36 KiB of LDS per wavefront (four wavefronts per CU, one per SIMD).
+template <int G>
+int stage_chunk(int N) {
+  constexpr int S = WAVE / G;
+  int c = (36 * 1024) / (2 * STAGE_ROWS * S * (int)sizeof(double));
+  if (c < 1) c = 1;
+  return c < N ? c : N;
+}
+
 template <int G>
 void launch_g(const SolveArgs& a, double* ws, hipStream_t stream) {
   constexpr int S = WAVE / G;
   const int blocks = (a.B + S - 1) / S;
-  hipLaunchKernelGGL((cilqr_solve_groups_kernel<G, false>), dim3(blocks), dim3(WAVE), 0, stream, a, ws);
-  hipLaunchKernelGGL((cilqr_solve_groups_kernel<G, true>), dim3(blocks), dim3(WAVE), 0, stream, a, ws);
+  const int chunk = stage_chunk<G>(a.N);
+  const size_t lds = (size_t)2 * chunk * STAGE_ROWS * S * sizeof(double);
+  hipLaunchKernelGGL((cilqr_solve_groups_kernel<G, false>), dim3(blocks), dim3(WAVE), lds, stream, a, ws, chunk);
+  hipLaunchKernelGGL((cilqr_solve_groups_kernel<G, true>), dim3(blocks), dim3(WAVE), 0, stream, a, ws, chunk);
 }
 
 }  // namespace
