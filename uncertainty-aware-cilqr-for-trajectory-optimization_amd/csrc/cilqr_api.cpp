@@ -272,12 +272,13 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
   a.B = B; a.N = N; a.M = M; a.flags = flags;
   a.kp = h->kp;
   HIP_TRY(hipSetDevice(h->device));
-  // Kernel family by batch size: up to ≈2 solves per SIMD one wavefront per solve (LDS-resident); above,
-  // G lanes per solve with G the power of two nearest below 65536/B, i.e. about one wavefront per SIMD of the 1024.
+  // Kernel family by batch size: up to ≈1.25 solves per SIMD one wavefront per solve (LDS-resident, 0.79 ms
+  // for 1024 solves of config 2 and growing with the second wavefront per SIMD); above, G lanes per solve with G the power of
+  // two nearest below 65536/B (at most 32), i.e. about one wavefront per SIMD of the 1024 (1.0 ms up to B = 2048).
   int G = 64;
   if (h->force_g == 1 || h->force_g == 2 || h->force_g == 4 || h->force_g == 8 || h->force_g == 16 || h->force_g == 32 || h->force_g == 64) {
     G = h->force_g;
-  } else if (B > 2048 && M <= 32) {
+  } else if (B > 1280 && M <= 32) {
     // (with hundreds of obstacle entries per step the solve is a stream over its obstacle table: the wavefront-per-solve
     // family reads it as whole 400-640 B rows per instruction and measures ≈2x faster there — BASELINE config 3)
     G = 32;

@@ -80,20 +80,22 @@ __device__ __forceinline__ void stage_copy(const double* src, double* dst, int n
     const unsigned long long piece = uniform64(src0 + (unsigned long long)off);
     const unsigned lds_byte = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)off));
     unsigned long long save;
-    unsigned vtmp;
+    unsigned vtmp, m0_save;
     asm volatile(
         "s_mov_b64 %0, exec\n\t"
-        "s_mov_b64 exec, %3\n\t"
+        "s_mov_b32 %2, m0\n\t"
+        "s_mov_b64 exec, %4\n\t"
         "v_mbcnt_lo_u32_b32 %1, -1, 0\n\t"
         "v_mbcnt_hi_u32_b32 %1, -1, %1\n\t"
         "v_lshlrev_b32 %1, 4, %1\n\t"
-        "s_mov_b32 m0, %4\n\t"
+        "s_mov_b32 m0, %5\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\t"
+        "s_mov_b32 m0, %2\n\t"
         "s_mov_b64 exec, %0"
-        : "=&s"(save), "=&v"(vtmp)
+        : "=&s"(save), "=&v"(vtmp), "=&s"(m0_save)
         : "s"(piece), "s"(mask), "s"(lds_byte)
-        : "memory", "m0");
+        : "memory");
   }
 }
 __device__ __forceinline__ void stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
