@@ -30,7 +30,9 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (cannot be collected inside this process): FETCH_SIZE
 # doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950, plus WRITE_SIZE.  Keyed by (workload, batch).
-PMC_TRAFFIC_BYTES = {("c2", 1024): 2 * 5645.43e3 + 2560e3,
+PMC_TRAFFIC_BYTES = {("c2", 1024): 2 * 5645.78e3 + 2560e3,      # profiles/r01_final_solver_summary.md
+                     ("c3", 4096): 2 * 208505e3 + 112781e3,     # compact sampled form (materialised: ≈ 23 GB)
+                     ("c5", 8192): 2 * 2.85e9 + 3.86883e9,      # the global workspace of the grouped family
                      # profiles/r01_wide_rows_summary.md (KB per dispatch): the 1024^2 destination reads a 512^2 patch of the source
                      ("warp", 1024): 2 * 598.438e3 + 4096e3,
                      ("occ", 8192): 2 * 131103e3 + 65536e3}
@@ -554,9 +556,10 @@ def main():
                        "batch_per_gpu": B, "horizon": N, "obstacles": M, "mean_reference_iterations": mean_iters,
                        "parallelism": "scene-sharded x%d, RCCL all-gather of (J,index)" % world},
             "roofline": {"bound": "hbm", "kernel": "cilqr_solve_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC_BYTES.get((args.workload, B)),
-                         "traffic_source": "profiles/r01_v4_solve_c2_summary.md (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
-                         if (args.workload, B) in PMC_TRAFFIC_BYTES else None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None if (args.workload == "c3" and args.materialised) else PMC_TRAFFIC_BYTES.get((args.workload, B)),
+                         "traffic_source": "profiles/r01_final_solver_summary.md (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+                         if (args.workload, B) in PMC_TRAFFIC_BYTES and not (args.workload == "c3" and args.materialised) else None,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch,
                          "note": "latency/fp64-VALU-bound path: HBM fraction is tiny by design (LDS-resident solve); see fp64_valu"},
             "fp64_valu": {"achieved_tflops_est": flops_solve * B / (kern_ms * 1e-3) / 1e12, "peak_tflops": FP64_VALU_PEAK_TF,

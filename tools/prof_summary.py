@@ -36,7 +36,7 @@ def main():
             acc = defaultdict(lambda: [0.0, 0])
             for f in pmc:
                 for r in csv.DictReader(open(f)):
-                    k = (short(r["Kernel_Name"], 60), r["Counter_Name"])
+                    k = (short(r["Kernel_Name"], 110), r["Counter_Name"])
                     acc[k][0] += float(r["Counter_Value"])
                     acc[k][1] += 1
             print("## `%s` — `rocprofv3 --pmc` (mean per dispatch)\n" % os.path.basename(d.rstrip("/")))

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Profiles the solver configurations on the GPU box: kernel-trace stats, then FETCH_SIZE / WRITE_SIZE in separate --pmc passes
+# (never combined with other trace domains).  Raw output under gpurun_out/prof_solver/, summary next to it.
+set -e
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_solver
+rm -rf $OUT && mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+for w in c2 c3 c5; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${w}_stats -o ${w} -- python3 $ROOT/bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline > $OUT/${w}_stats.log 2>&1
+  echo "stats $w done"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --output-format csv -d $OUT/${w}_pmc_$c -o ${w} -- python3 $ROOT/bench.py --workload $w --steps 4 --warmup 1 --no-cpu-baseline > $OUT/${w}_pmc_$c.log 2>&1
+    echo "pmc $w $c done"
+  done
+done
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/c2_pmc_SQ -o c2 -- python3 $ROOT/bench.py --workload c2 --steps 4 --warmup 1 --no-cpu-baseline > $OUT/c2_pmc_SQ.log 2>&1
+cd $ROOT
+python3 tools/prof_summary.py "r01 (final build of the round) — solver configurations 2, 3 (compact sampled obstacles), 5" \
+  $OUT/c2_stats $OUT/c3_stats $OUT/c5_stats $OUT/c2_pmc_FETCH_SIZE $OUT/c2_pmc_WRITE_SIZE $OUT/c3_pmc_FETCH_SIZE $OUT/c3_pmc_WRITE_SIZE \
+  $OUT/c5_pmc_FETCH_SIZE $OUT/c5_pmc_WRITE_SIZE $OUT/c2_pmc_SQ > $ROOT/gpurun_out/prof_solver_summary.md
+du -sh $OUT
