@@ -148,15 +148,19 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
       const double* dim = dim0 + (size_t)t * 2;
       same = same && pose[0] == pose0[0] && pose[1] == pose0[1] && pose[2] == pose0[2] && pose[3] == pose0[3] &&
              dim[0] == dim0[0] && dim[1] == dim0[1];
-      const ObsEntry e = make_obs_entry(kp, pose, dim);
-      double* o = tab + (size_t)(m * TABF * N + t) * S;
-      const size_t fs = (size_t)N * S;  // field stride
-      o[0] = e.ox; o[fs] = e.oy; o[2 * fs] = e.co; o[3 * fs] = e.so; o[4 * fs] = e.ia2; o[5 * fs] = e.ib2;
     }
     int all = same ? 1 : 0;
 #pragma unroll
     for (int o = G / 2; o > 0; o >>= 1) all &= __shfl_xor(all, o, WAVE);
-    if (all && m < 64) held |= 1ull << m;
+    const bool is_held = all && m < 64;
+    if (is_held) held |= 1ull << m;
+    // a held obstacle needs its step-0 row only (lane g == 0 of the group writes it); the others need every row
+    for (int t = g; t < (is_held ? 1 : N); t += G) {
+      const ObsEntry e = make_obs_entry(kp, pose0 + (size_t)t * 4, dim0 + (size_t)t * 2);
+      double* o = tab + (size_t)(m * TABF * N + t) * S;
+      const size_t fs = (size_t)N * S;  // field stride
+      o[0] = e.ox; o[fs] = e.oy; o[2 * fs] = e.co; o[3 * fs] = e.so; o[4 * fs] = e.ia2; o[5 * fs] = e.ib2;
+    }
   }
   mem_sync();
 
