@@ -283,7 +283,12 @@ struct Rec {
 // I/Model.cpp:100-155).  (px,py,v,ct,st): state t with cos/sin of its heading; (vn,cn,sn): speed and cos/sin heading of
 // state t+1; (cx,cy): closest path sample.  `obs(m, e, w)` supplies obstacle m at this step and its weight.
 // Returns the stage cost of get_J.
-template <typename ObsAt>
+// CULL (one wavefront per solve only: the lanes of a vote are the timesteps of ONE trajectory): an entry whose barrier
+// exponent q2·c is below -64 on both ego circles for every step of the wavefront contributes less than e^-64 ≈ 1.6e-28 times
+// O(10) factors to any sum — it is skipped after the 22 instructions that establish this, before its two exponentials.  The
+// gradient and Hessian sums it would have been added to are O(1e-3 … 1e3): the omission is below 1e-26 absolute, i.e. far
+// below one ulp of anything it feeds (measured: max|ΔU| against the oracle unchanged).  NaN exponents never vote to skip.
+template <bool CULL = false, typename ObsAt>
 __device__ __forceinline__ double lin_step(const KParams& kp, double px, double py, double v, double ct, double st, double u0,
                                            double u1, double vn, double cn, double sn, double cx, double cy, int M, ObsAt obs,
                                            Rec& r) {
@@ -304,18 +309,28 @@ __device__ __forceinline__ double lin_step(const KParams& kp, double px, double 
   const double svf = -2 * (kp.q2_front * kp.q1_front), smf = 4 * (kp.q2_front * kp.q2_front * kp.q1_front);
   const double svr = -2 * (kp.q2_rear * kp.q1_rear), smr = 4 * (kp.q2_rear * kp.q2_rear * kp.q1_rear);
   auto add_entry = [&](const ObsEntry& e, double w) {
-    double gx = 0.0, gy = 0.0, gxx = 0.0, gxy = 0.0, gyy = 0.0;
+    // both circles up to the barrier argument c = 1 - d'Pd (I/Obstacle.cpp:65-73, 86-94)
+    double d0[2], d1[2], g0[2], g1[2], arg[2];
 #pragma unroll
     for (int side = 0; side < 2; ++side) {
       const double ex = (side == 0 ? fxp : rxp) - e.ox, ey = (side == 0 ? fyp : ryp) - e.oy;
-      const double q2 = side == 0 ? kp.q2_front : kp.q2_rear;
-      const double d0 = e.co * ex + e.so * ey;
-      const double d1 = e.co * ey - e.so * ex;
-      const double g0 = d0 * e.ia2, g1 = d1 * e.ib2;
-      const double c = 1 - (g0 * d0 + g1 * d1);
-      const double h0 = e.co * g0 - e.so * g1;  // c-dot = -2 (h0, h1)
-      const double h1 = e.so * g0 + e.co * g1;
-      const double ee = exp_fast(q2 * c);
+      d0[side] = e.co * ex + e.so * ey;
+      d1[side] = e.co * ey - e.so * ex;
+      g0[side] = d0[side] * e.ia2;
+      g1[side] = d1[side] * e.ib2;
+      const double c = 1 - (g0[side] * d0[side] + g1[side] * d1[side]);
+      arg[side] = (side == 0 ? kp.q2_front : kp.q2_rear) * c;
+    }
+    if (CULL) {
+      const bool needed = !(arg[0] <= -64.0) || !(arg[1] <= -64.0);
+      if (__builtin_amdgcn_ballot_w64(needed) == 0) return;
+    }
+    double gx = 0.0, gy = 0.0, gxx = 0.0, gxy = 0.0, gyy = 0.0;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      const double h0 = e.co * g0[side] - e.so * g1[side];  // c-dot = -2 (h0, h1)
+      const double h1 = e.so * g0[side] + e.co * g1[side];
+      const double ee = exp_fast(arg[side]);
       const double sv = (side == 0 ? svf : svr) * ee;
       const double sm = (side == 0 ? smf : smr) * ee;
       gx += sv * h0;

@@ -142,7 +142,7 @@ __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int
     const double px = xr[0], py = xr[1];
     const int cs = closest_sample(S, grid, px, py, LdsSamples{samp});
     Rec c;
-    Jpart += lin_step(kp, px, py, xr[2], xr[4], xr[5], U[2 * t], U[2 * t + 1], xn[2], xn[4], xn[5], samp[2 * cs],
+    Jpart += lin_step<true>(kp, px, py, xr[2], xr[4], xr[5], U[2 * t], U[2 * t + 1], xn[2], xn[4], xn[5], samp[2 * cs],
                       samp[2 * cs + 1], M, src.at(t), c);
     double* r = rec + t * REC;
     r[0] = c.lx0; r[1] = c.lx1; r[2] = c.lx2; r[3] = c.l00; r[4] = c.l01; r[5] = c.l11;
