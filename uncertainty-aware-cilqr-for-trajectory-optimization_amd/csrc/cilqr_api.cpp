@@ -337,6 +337,8 @@ int cilqr_solve_batch_sampled_device(cilqr_handle* h, void* stream, int B, int N
     return fail(CILQR_ERR_ARG, "cilqr_solve_batch_sampled: null required pointer");
   if (cilqr::solve_lds_bytes(N, h->kp.n_samples) + cilqr::solve_sampled_lds_bytes(n_obs, n_samples) > cilqr::SOLVE_LDS_MAX)
     return fail(CILQR_ERR_UNSUPPORTED, "cilqr_solve_batch_sampled: n_obs * n_samples offset records do not fit LDS beside the solve");
+  if (cilqr::solve_sampled_tab_doubles(n_obs, N) > (size_t)h->max_obstacles * 6 * (size_t)h->max_horizon)
+    return fail(CILQR_ERR_UNSUPPORTED, "cilqr_solve_batch_sampled: nominal records exceed the obstacle workspace reserved at create");
   cilqr::SolveArgs a;
   a.x0 = x0; a.U = U; a.poly = poly; a.xplan_fl = xplan_fl;
   a.obs_pose = nom_pose; a.obs_dim = nom_dim; a.obs_weight = nullptr;
