@@ -780,3 +780,44 @@ def test_long_horizons(cilqr, oracle):
                                   np.zeros((2, 8, 256, 3)), 1.0 / 256)
     finally:
         s.close()
+
+
+@pytest.mark.parametrize("G", [0, 8])
+def test_closest_point_windows_on_steep_and_distant_paths(cilqr, oracle, G, monkeypatch):
+    """The closest-sample search prunes with two windows (x side, y side; cilqr_device.hpp::closest_sample); both must return
+    exactly the reference's argmin over all 200 samples.  Stress them away from the benchmark's gentle paths: slopes up
+    to ±2 (the y-side bound must switch itself off), flat paths (adjacent samples equal in y), egos up to 6 m beside the
+    path and beyond either end of it — whole solves against the oracle, both kernel families."""
+    from cilqr_amd import scenes
+    if G:
+        monkeypatch.setenv("CILQR_FORCE_G", str(G))
+    N, M, B = 50, 2, 192
+    p = cilqr.default_params(N)
+    sc = scenes.make_static(B, N, M, p, 4242)
+    rng = np.random.default_rng(4243)
+    poly = np.zeros((B, 6))
+    slope = rng.uniform(-2.0, 2.0, B)
+    slope[:32] = 0.0                                   # flat: D = 0
+    curv = rng.uniform(-0.02, 0.02, B)
+    curv[:48] = 0.0
+    xf = sc["xplan_fl"][:, 0]
+    # y(x) = y0 + slope (x - xf) + curv (x - xf)^2, expanded in powers of x
+    y0 = rng.uniform(-3, 3, B)
+    poly[:, 0] = y0 - slope * xf + curv * xf * xf
+    poly[:, 1] = slope - 2 * curv * xf
+    poly[:, 2] = curv
+    x0 = sc["x0"].copy()
+    along = rng.uniform(-8.0, 28.0, B)                 # before the first sample … beyond the last (the plan spans ≈ 19 m)
+    x0[:, 0] = xf + along
+    x0[:, 1] = y0 + slope * along + curv * along * along + rng.uniform(-6.0, 6.0, B)
+    x0[:, 3] = np.arctan(slope) + rng.uniform(-0.3, 0.3, B)
+    sc2 = dict(sc, poly=poly, x0=x0)
+    s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M, device=0)
+    try:
+        got = _gpu_batch(s, sc2)
+    finally:
+        s.close()
+    want = _oracle_batch(oracle, N, sc2)
+    ok = np.isfinite(want["U"]).all(axis=1)
+    assert ok.sum() >= B * 0.9
+    _compare({k: v[ok] for k, v in got.items()}, {k: v[ok] for k, v in want.items()}, 1e-8, "closest-point windows G=%d" % G)

@@ -192,12 +192,14 @@ __device__ __forceinline__ void forward_step(const FwdConst& k, const FwdIn& c, 
 // bit-identical samples.
 struct SampleGrid {
   double xf, dxs, inv_dxs;  // inv_dxs = 1/dxs (signed)
+  double dmax;              // largest |y_{s+1} - y_s| over the samples (set once per solve; +inf: not known)
   bool windowed;            // false: dxs is 0 or not finite → full scan
 };
 __device__ __forceinline__ void make_sample_grid(SampleGrid& g, double xf, double xl, int S) {
   g.xf = xf;
   g.dxs = (xl - xf) / (double)S;
   g.inv_dxs = 1.0 / g.dxs;
+  g.dmax = __builtin_huge_val();
   g.windowed = fabs(g.inv_dxs) < 1.0e300 && fabs(g.dxs) < 1.0e300 && g.dxs != 0.0;
 }
 __device__ __forceinline__ void sample_xy(const SampleGrid& g, const double* pc, int s, double& x, double& y) {
@@ -228,11 +230,31 @@ __device__ __forceinline__ int closest_sample(int S, const SampleGrid& g, double
   if (g.windowed) {
     const double fc = (px - g.xf) * g.inv_dxs;
     const double fcc = fmin(fmax(fc, 0.0), (double)(S - 1));  // NaN → 0
-    const double dc = dist((int)(fcc + 0.5));
+    const int c = (int)(fcc + 0.5);
+    double scx, scy;
+    at(c, scx, scy);
+    const double dc = dist(c);
     const double hw = (double)(__builtin_sqrtf((float)dc) * 1.0001f) * fabs(g.inv_dxs) * 1.0001 + 2.0;
     if (hw < 1.0e9) {  // false for NaN / overflow: keep the full range
       lo = (int)fmin(fmax(fc - hw, 0.0), (double)(S - 1));
       hi = (int)fmax(fmin(fc + hw + 1.0, (double)(S - 1)), 0.0);
+      // Second, usually much tighter window from the y side.  Sample c + n (or c - n) has |x_s - px| ≥ n·h - e and, by the
+      // triangle inequality over adjacent samples, |y_s - py| ≥ Ly - n·D, with h = |dxs|, e = |x_c - px|, Ly = |y_c - py|,
+      // D = dmax.  While both right-hand sides are non-negative, d_s ≥ (n h - e)² + (Ly - n D)²; a sample can only reach
+      // d_c if that is ≤ d_c, i.e. n ≤ [B + sqrt(B² + A (T - e² - Ly²))] / A with A = h² + D², B = h e + Ly D.  Used only when
+      // the y-bound stays non-negative across the whole first window (D·hw ≤ Ly) and c really is the sample nearest in x
+      // (e ≤ h); widened by a 1e-9 relative margin and two samples, like the first window ≫ any rounding in its terms.
+      const double h = fabs(g.dxs), D = g.dmax, e = fabs(scx - px), Ly = fabs(scy - py);
+      if (D * hw <= Ly && e <= h) {
+        const double A = h * h + D * D, Bq = h * e + Ly * D;
+        const double T = dc * (1.0 + 1.0e-9);
+        const double disc = Bq * Bq + A * (T - e * e - Ly * Ly);
+        const double nmax = (Bq + sqrt(fmax(disc, 0.0))) / A * (1.0 + 1.0e-9) + 2.0;
+        if (nmax < 1.0e9) {  // false for NaN
+          lo = max(lo, (int)fmax((double)c - nmax, 0.0));
+          hi = min(hi, (int)fmin((double)c + nmax + 1.0, (double)(S - 1)));
+        }
+      }
     }
   }
   double md = dist(lo);

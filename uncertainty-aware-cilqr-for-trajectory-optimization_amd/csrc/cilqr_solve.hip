@@ -43,6 +43,12 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, WAVE));
+  return v;
+}
+
 __device__ __forceinline__ void store_state(double* X, int t, const State& s) {
   double* r = X + t * XR;
   r[0] = s.x; r[1] = s.y; r[2] = s.v; r[3] = s.th; r[4] = s.c; r[5] = s.s;
@@ -374,6 +380,14 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
     }
   }
   __syncthreads();
+  {  // largest step between adjacent path samples in y: closest_sample's second window (cilqr_device.hpp)
+    double m = 0.0;
+    for (int q = lane; q + 1 < S; q += WAVE) {
+      const double d = fabs(samp[2 * (q + 1) + 1] - samp[2 * q + 1]);
+      m = fmax(m, d == d ? d : __builtin_huge_val());
+    }
+    grid.dmax = readfirstlane_f64(wave_max(m));
+  }
 
   bool handover = false;  // fast kernel only: this solve needs the GENERAL kernel
   if (GENERAL) {          // nominal rollout, I/iLQR.cpp:51-62

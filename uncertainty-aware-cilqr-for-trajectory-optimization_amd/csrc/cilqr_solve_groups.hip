@@ -127,6 +127,19 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
   SampleGrid grid;
   make_sample_grid(grid, a.xplan_fl[2 * b], a.xplan_fl[2 * b + 1], NS);
   auto sample_at = [&](int s, double& x, double& y) { sample_xy(grid, pc, s, x, y); };
+  {  // largest step between adjacent path samples in y: closest_sample's second window (cilqr_device.hpp)
+    double m = 0.0;
+    for (int q = g; q + 1 < NS; q += G) {
+      double x0_, y0_, x1_, y1_;
+      sample_xy(grid, pc, q, x0_, y0_);
+      sample_xy(grid, pc, q + 1, x1_, y1_);
+      const double d = fabs(y1_ - y0_);
+      m = fmax(m, d == d ? d : __builtin_huge_val());
+    }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, WAVE));
+    grid.dmax = m;
+  }
 
   double* Ug = a.U + (size_t)b * 2 * N;
   for (int t = g; t < N; t += G) {
