@@ -227,24 +227,38 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
     // ---- phase L: this group's N steps over its G lanes
     unsigned long long t0 = a.diag ? __builtin_readcyclecounter() : 0;
     double Jpart = 0.0;
-    for (int t = g; t < N; t += G) {
-      const double px = XF(xc, t, 0), py = XF(xc, t, 1);
-      const int cs = closest_sample(NS, grid, px, py, sample_at);
-      double cx, cy;
-      sample_xy(grid, pc, cs, cx, cy);
-      const size_t fs = (size_t)N * S;
-      auto obs = [&](int m, ObsEntry& e, double& w) {
-        const double* p = tab + (size_t)(((m < 64 && ((held >> m) & 1)) ? 0 : t)) * S + (size_t)m * TABF * fs;
-        e.ox = p[0]; e.oy = p[fs]; e.co = p[2 * fs]; e.so = p[3 * fs]; e.ia2 = p[4 * fs]; e.ib2 = p[5 * fs];
-        w = wts ? wts[m] : kp.w_obstacle;
+    {
+      // this lane's steps t = g, g+G, …: the ten operands of the next one are requested while the current one computes
+      struct LIn { double px, py, v, ct, st, u0, u1, vn, cn, sn; };
+      auto load_in = [&](LIn& o, int t) {
+        const double* xr = &XF(xc, t, 0);
+        const double* xq = &XF(xc, t + 1, 0);
+        const double* ur = &UF(uc, t, 0);
+        o.px = xr[0]; o.py = xr[S]; o.v = xr[2 * S]; o.ct = xr[4 * S]; o.st = xr[5 * S];
+        o.u0 = ur[0]; o.u1 = ur[S];
+        o.vn = xq[2 * S]; o.cn = xq[4 * S]; o.sn = xq[5 * S];
       };
-      Rec c;
-      Jpart += lin_step(kp, px, py, XF(xc, t, 2), XF(xc, t, 4), XF(xc, t, 5), UF(uc, t, 0), UF(uc, t, 1), XF(xc, t + 1, 2),
-                        XF(xc, t + 1, 4), XF(xc, t + 1, 5), cx, cy, M, obs, c);
-      double* r = &RF(t, 0);
-      r[0] = c.lx0; r[S] = c.lx1; r[2 * S] = c.lx2; r[3 * S] = c.l00; r[4 * S] = c.l01; r[5 * S] = c.l11;
-      r[6 * S] = c.lu0; r[7 * S] = c.lu1; r[8 * S] = c.luu0; r[9 * S] = c.luu1;
-      r[10 * S] = c.al; r[11 * S] = c.be; r[12 * S] = c.ga; r[13 * S] = c.de; r[14 * S] = c.p; r[15 * S] = c.q;
+      LIn cur, nxt;
+      if (g < N) load_in(cur, g);
+      for (int t = g; t < N; t += G) {
+        if (t + G < N) load_in(nxt, t + G);
+        const int cs = closest_sample(NS, grid, cur.px, cur.py, sample_at);
+        double cx, cy;
+        sample_xy(grid, pc, cs, cx, cy);
+        const size_t fs = (size_t)N * S;
+        auto obs = [&](int m, ObsEntry& e, double& w) {
+          const double* p = tab + (size_t)(((m < 64 && ((held >> m) & 1)) ? 0 : t)) * S + (size_t)m * TABF * fs;
+          e.ox = p[0]; e.oy = p[fs]; e.co = p[2 * fs]; e.so = p[3 * fs]; e.ia2 = p[4 * fs]; e.ib2 = p[5 * fs];
+          w = wts ? wts[m] : kp.w_obstacle;
+        };
+        Rec c;
+        Jpart += lin_step(kp, cur.px, cur.py, cur.v, cur.ct, cur.st, cur.u0, cur.u1, cur.vn, cur.cn, cur.sn, cx, cy, M, obs, c);
+        double* r = &RF(t, 0);
+        r[0] = c.lx0; r[S] = c.lx1; r[2 * S] = c.lx2; r[3 * S] = c.l00; r[4 * S] = c.l01; r[5 * S] = c.l11;
+        r[6 * S] = c.lu0; r[7 * S] = c.lu1; r[8 * S] = c.luu0; r[9 * S] = c.luu1;
+        r[10 * S] = c.al; r[11 * S] = c.be; r[12 * S] = c.ga; r[13 * S] = c.de; r[14 * S] = c.p; r[15 * S] = c.q;
+        cur = nxt;
+      }
     }
     J_new = group_sum<G>(Jpart);
     j_valid = true;
