@@ -114,7 +114,8 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
 
   // column `grp` of this wavefront's block: element (row r) at ws[r * S]
   double* ws = ws_base + (size_t)blockIdx.x * L.rows() * S + grp;
-  double* tab = a.obs_tab + (size_t)blockIdx.x * ((size_t)M * N * TABF) * S + grp;  // rows ((m*6 + f)*N + t)
+  // obstacle table of this wavefront: entry (m, t, solve) = 6 contiguous doubles at ((m*N + t)*S + solve)*6
+  double* tab = a.obs_tab + (size_t)blockIdx.x * ((size_t)M * N * TABF) * S + (size_t)grp * TABF;
 #define XF(base, t, f) ws[(size_t)((base) + (t) * XR + (f)) * S]  /* state arrays: (N+1) steps x 6 fields */
 #define UF(base, t, f) ws[(size_t)((base) + (t) * 2 + (f)) * S]   /* control arrays: N steps x 2 fields */
 #define RF(t, f) ws[(size_t)(L.rec() + (t) * REC + (f)) * S]      /* linearisation: N steps x 16 fields */
@@ -170,9 +171,8 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
     // a held obstacle needs its step-0 row only (lane g == 0 of the group writes it); the others need every row
     for (int t = g; t < (is_held ? 1 : N); t += G) {
       const ObsEntry e = make_obs_entry(kp, pose0 + (size_t)t * 4, dim0 + (size_t)t * 2);
-      double* o = tab + (size_t)(m * TABF * N + t) * S;
-      const size_t fs = (size_t)N * S;  // field stride
-      o[0] = e.ox; o[fs] = e.oy; o[2 * fs] = e.co; o[3 * fs] = e.so; o[4 * fs] = e.ia2; o[5 * fs] = e.ib2;
+      double* o = tab + (size_t)(m * N + t) * S * TABF;
+      o[0] = e.ox; o[1] = e.oy; o[2] = e.co; o[3] = e.so; o[4] = e.ia2; o[5] = e.ib2;
     }
   }
   mem_sync();
@@ -245,10 +245,12 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
         const int cs = closest_sample(NS, grid, cur.px, cur.py, sample_at);
         double cx, cy;
         sample_xy(grid, pc, cs, cx, cy);
-        const size_t fs = (size_t)N * S;
+        // one 48-byte entry = three 16-byte loads from one address; a held obstacle reads its step-0 entry
         auto obs = [&](int m, ObsEntry& e, double& w) {
-          const double* p = tab + (size_t)(((m < 64 && ((held >> m) & 1)) ? 0 : t)) * S + (size_t)m * TABF * fs;
-          e.ox = p[0]; e.oy = p[fs]; e.co = p[2 * fs]; e.so = p[3 * fs]; e.ia2 = p[4 * fs]; e.ib2 = p[5 * fs];
+          const int row = (m < 64 && ((held >> m) & 1)) ? 0 : t;
+          const double2* p = reinterpret_cast<const double2*>(tab + ((size_t)m * N + row) * S * TABF);
+          const double2 q0 = p[0], q1 = p[1], q2 = p[2];
+          e.ox = q0.x; e.oy = q0.y; e.co = q1.x; e.so = q1.y; e.ia2 = q2.x; e.ib2 = q2.y;
           w = wts ? wts[m] : kp.w_obstacle;
         };
         Rec c;
