@@ -30,9 +30,9 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (cannot be collected inside this process): FETCH_SIZE
 # doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950, plus WRITE_SIZE.  Keyed by (workload, batch).
-PMC_TRAFFIC_BYTES = {("c2", 1024): 2 * 5645.78e3 + 2560e3,      # profiles/r01_final_solver_summary.md
-                     ("c3", 4096): 2 * 208505e3 + 112781e3,     # compact sampled form (materialised: ≈ 23 GB)
-                     ("c5", 8192): 2 * 2.85e9 + 3.86883e9,      # the global workspace of the grouped family
+PMC_TRAFFIC_BYTES = {("c2", 1024): 2 * 5657.96e3 + 2560e3,      # profiles/r01_final_solver_summary.md
+                     ("c3", 4096): 2 * 213649e3 + 112780e3,     # compact sampled form (materialised: ≈ 23 GB)
+                     ("c5", 8192): 2 * 2.51843e9 + 3.38345e9,   # the global workspace of the grouped family
                      # profiles/r01_wide_rows_summary.md (KB per dispatch): the 1024^2 destination reads a 512^2 patch of the source
                      ("warp", 1024): 2 * 598.438e3 + 4096e3,
                      ("occ", 8192): 2 * 131103e3 + 65536e3}
