@@ -5,6 +5,8 @@
 // I/ = CILQR/src/ilqr/include/ilqr/ of Leo-Liao-Chao/Uncertainty-Aware-CILQR-for-Trajectory-Optimization.
 #pragma once
 
+#include <stddef.h>
+
 #include <float.h>
 
 #include "cilqr_internal.h"
@@ -34,6 +36,18 @@ __device__ __forceinline__ double vmax(double a, double b) {
 }
 // Pins a loop-invariant value in a vector register: after this the compiler cannot fold it back into a literal.
 #define CILQR_PIN(x) asm volatile("" : "+v"(x))
+
+// The parameter block as it lies in the kernel-argument segment (SolveArgs is the first kernel parameter of every solve
+// kernel), through a pointer the compiler cannot trace back to the preloaded arguments.  A phase that reads its parameters
+// through this keeps their scalar registers live for that phase only; read once at kernel entry, the 35 doubles are carried
+// — and spilled to vector lanes, one v_readlane per use — across every phase (grouped family: 215 → 122 spilled SGPRs,
+// 44 → 16 reloads per pair of obstacle entries).
+__device__ __forceinline__ const KParams& phase_params() {
+  const KParams* q = reinterpret_cast<const KParams*>(
+      reinterpret_cast<const char*>((const void*)__builtin_amdgcn_kernarg_segment_ptr()) + offsetof(SolveArgs, kp));
+  asm volatile("" : "+s"(q));
+  return *q;
+}
 
 // 1/x by v_rcp_f64 and two Newton steps (≤ ~1 ulp; x is a well-scaled positive determinant here).
 __device__ __forceinline__ double rcp_newton(double x) {

@@ -422,8 +422,9 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
     // The linearisation and J share their closest-point searches, so they are computed together, first.
     {
       double part;
-      if (TAB == 2) part = linearize(kp, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, SampledSource{tab, off, N, a.n_samples, M, a.samp_w});
-      else part = linearize(kp, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, TabSource{tab, wts, N, kp.w_obstacle});
+      const KParams kpl = phase_params();  // phase-local read of the parameter block (cilqr_device.hpp)
+      if (TAB == 2) part = linearize(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, SampledSource{tab, off, N, a.n_samples, M, a.samp_w});
+      else part = linearize(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, TabSource{tab, wts, N, kpl.w_obstacle});
       J_new = readfirstlane_f64(wave_sum(part));
     }
     j_valid = true;

@@ -238,6 +238,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
         o.u0 = ur[0]; o.u1 = ur[S];
         o.vn = xq[2 * S]; o.cn = xq[4 * S]; o.sn = xq[5 * S];
       };
+      const KParams kpl = phase_params();  // this phase's own read of the parameter block (cilqr_device.hpp)
       LIn cur, nxt;
       if (g < N) load_in(cur, g);
       for (int t = g; t < N; t += G) {
@@ -251,10 +252,10 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
           const double2* p = reinterpret_cast<const double2*>(tab + ((size_t)m * N + row) * S * TABF);
           const double2 q0 = p[0], q1 = p[1], q2 = p[2];
           e.ox = q0.x; e.oy = q0.y; e.co = q1.x; e.so = q1.y; e.ia2 = q2.x; e.ib2 = q2.y;
-          w = wts ? wts[m] : kp.w_obstacle;
+          w = wts ? wts[m] : kpl.w_obstacle;
         };
         Rec c;
-        Jpart += lin_step(kp, cur.px, cur.py, cur.v, cur.ct, cur.st, cur.u0, cur.u1, cur.vn, cur.cn, cur.sn, cx, cy, M, obs, c);
+        Jpart += lin_step(kpl, cur.px, cur.py, cur.v, cur.ct, cur.st, cur.u0, cur.u1, cur.vn, cur.cn, cur.sn, cx, cy, M, obs, c);
         double* r = &RF(t, 0);
         r[0] = c.lx0; r[S] = c.lx1; r[2 * S] = c.lx2; r[3 * S] = c.l00; r[4 * S] = c.l01; r[5 * S] = c.l11;
         r[6 * S] = c.lu0; r[7 * S] = c.lu1; r[8 * S] = c.luu0; r[9 * S] = c.luu1;
