@@ -456,7 +456,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
     if (DIAG) ++n_R;
     if (GENERAL) {
       forward_general(kp, N, Xc, Uc, kK, Xn, Un);
-    } else if (!forward_fast(kp, N, Xc, Uc, kK, Xn, Un)) {
+    } else if (!forward_fast(KParams(phase_params()), N, Xc, Uc, kK, Xn, Un)) {
       handover = true;
       break;
     }

@@ -386,7 +386,8 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
         }
       } else {
         FwdConst k;
-        make_fwd_const(k, kp);
+        const KParams kpf = phase_params();
+        make_fwd_const(k, kpf);
         double max_th = fabs(s.th);
         FwdIn fa, fb;
         auto step = [&](const FwdIn& c, int i) {
