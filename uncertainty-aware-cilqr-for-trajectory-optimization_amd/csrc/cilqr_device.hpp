@@ -49,6 +49,13 @@ __device__ __forceinline__ const KParams& phase_params() {
   return *q;
 }
 
+// The whole argument block the same way (the epilogue's output pointers need not stay live through the iteration loop).
+__device__ __forceinline__ const SolveArgs& phase_args() {
+  const SolveArgs* q = reinterpret_cast<const SolveArgs*>((const void*)__builtin_amdgcn_kernarg_segment_ptr());
+  asm volatile("" : "+s"(q));
+  return *q;
+}
+
 // 1/x by v_rcp_f64 and two Newton steps (≤ ~1 ulp; x is a well-scaled positive determinant here).
 __device__ __forceinline__ double rcp_newton(double x) {
   double r = __builtin_amdgcn_rcp(x);

@@ -476,22 +476,24 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   }
 
   if (!GENERAL) {
-    if (lane == 0) a.redo[b] = handover ? 1 : 0;
+    if (lane == 0) phase_args().redo[b] = handover ? 1 : 0;
     if (handover) return;  // outputs (and the in/out U) untouched: the GENERAL kernel starts from the same inputs
   }
 
   // ---- epilogue: X_result / U_result (:243-244) ----------------------------------------------------------------
   __syncthreads();
-  for (int i = lane; i < 2 * N; i += WAVE) Ug[i] = Uc[i];
-  double* Xg = a.X_out + (size_t)b * 4 * (N + 1);
+  const SolveArgs ae = phase_args();  // output pointers read here, not carried through the loop (cilqr_device.hpp)
+  double* Uo = ae.U + (size_t)b * 2 * N;
+  for (int i = lane; i < 2 * N; i += WAVE) Uo[i] = Uc[i];
+  double* Xg = ae.X_out + (size_t)b * 4 * (N + 1);
   for (int i = lane; i < 4 * (N + 1); i += WAVE) Xg[i] = Xc[(i >> 2) * XR + (i & 3)];
-  if (a.J_out) {
-    if (!j_valid) J_new = readfirstlane_f64(wave_sum(cost_only(kp, N, lane, samp, S, grid, Xc, Uc)));
-    if (lane == 0) a.J_out[b] = J_new;
+  if (ae.J_out) {
+    if (!j_valid) J_new = readfirstlane_f64(wave_sum(cost_only(ae.kp, N, lane, samp, S, grid, Xc, Uc)));
+    if (lane == 0) ae.J_out[b] = J_new;
   }
   if (lane == 0) {
-    if (a.iters_out) a.iters_out[b] = iters;
-    if (a.status_out) a.status_out[b] = status;
+    if (ae.iters_out) ae.iters_out[b] = iters;
+    if (ae.status_out) ae.status_out[b] = status;
   }
   if (DIAG && lane == 0 && a.diag) {
     const unsigned long long now_ = __builtin_readcyclecounter();

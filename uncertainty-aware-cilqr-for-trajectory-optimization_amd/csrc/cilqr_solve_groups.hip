@@ -108,6 +108,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
   const int b = blockIdx.x * S + grp;
   if (b >= a.B) return;  // whole groups leave together
   if (GENERAL && a.redo[b] == 0) return;
+  const SolveArgs* aq = &phase_args();  // taken while the wavefront is still whole; read in the epilogue
   const KParams kp = a.kp;
   const int N = a.N, M = a.M, NS = kp.n_samples;
   const WsLayout L{N, M};
@@ -455,21 +456,23 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
   }
 
   if (!GENERAL) {
-    if (g == 0) a.redo[b] = handover ? 1 : 0;
+    if (g == 0) aq->redo[b] = handover ? 1 : 0;
     if (handover) return;
   }
 
   // ---- epilogue: X_result / U_result (:243-244)
+  const SolveArgs ae = *aq;  // output pointers read here, not carried through the loop (cilqr_device.hpp::phase_args)
+  double* Uo = ae.U + (size_t)b * 2 * N;
   for (int t = g; t < N; t += G) {
-    Ug[2 * t] = UF(uc, t, 0);
-    Ug[2 * t + 1] = UF(uc, t, 1);
+    Uo[2 * t] = UF(uc, t, 0);
+    Uo[2 * t + 1] = UF(uc, t, 1);
   }
-  double* Xg = a.X_out + (size_t)b * 4 * (N + 1);
+  double* Xg = ae.X_out + (size_t)b * 4 * (N + 1);
   for (int t = g; t <= N; t += G) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) Xg[4 * t + r] = XF(xc, t, r);
   }
-  if (a.J_out) {
+  if (ae.J_out) {
     if (!j_valid) {
       double Jpart = 0.0;
       for (int t = g; t < N; t += G) {
@@ -477,19 +480,19 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
         const int cs = closest_sample(NS, grid, px, py, sample_at);
         double cx, cy;
         sample_xy(grid, pc, cs, cx, cy);
-        Jpart += stage_cost(kp, px - cx, py - cy, XF(xc, t, 2) - kp.desired_speed, UF(uc, t, 0), UF(uc, t, 1));
+        Jpart += stage_cost(ae.kp, px - cx, py - cy, XF(xc, t, 2) - ae.kp.desired_speed, UF(uc, t, 0), UF(uc, t, 1));
       }
       J_new = group_sum<G>(Jpart);
     }
-    if (g == 0) a.J_out[b] = J_new;
+    if (g == 0) ae.J_out[b] = J_new;
   }
   if (a.diag && g == 0) {  // {prologue, L, R, F, epilogue, #L, #R, total}: prologue/epilogue not separated here
     unsigned long long* d = a.diag + (size_t)b * 8;
     d[0] = 0; d[1] = tL; d[2] = tR; d[3] = tF; d[4] = 0; d[5] = nL; d[6] = nR; d[7] = __builtin_readcyclecounter() - t_begin;
   }
   if (g == 0) {
-    if (a.iters_out) a.iters_out[b] = iters;
-    if (a.status_out) a.status_out[b] = status;
+    if (ae.iters_out) ae.iters_out[b] = iters;
+    if (ae.status_out) ae.status_out[b] = status;
   }
 #undef XF
 #undef UF
