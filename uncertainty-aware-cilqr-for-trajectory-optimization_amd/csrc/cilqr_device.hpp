@@ -388,18 +388,20 @@ __device__ __forceinline__ double lin_step(const KParams& kp, double px, double 
     h01 += gxy * w;
     h11 += gyy * w;
   };
-  // two entries in flight, alternating registers: the next entry's loads fly while this one computes
+  // two entries in flight, alternating registers: the next entry's loads fly while this one computes.  `obs` returns false
+  // for an entry it has already established to be negligible (SampledObstacles: a whole far obstacle at once).
   ObsEntry ea, eb;
   double wa = 0.0, wb = 0.0;
-  if (M > 0) obs(0, ea, wa);
+  bool va = false, vb = false;
+  if (M > 0) va = obs(0, ea, wa);
   int m = 0;
   for (; m + 1 < M; m += 2) {
-    obs(m + 1, eb, wb);
-    add_entry(ea, wa);
-    if (m + 2 < M) obs(m + 2, ea, wa);
-    add_entry(eb, wb);
+    vb = obs(m + 1, eb, wb);
+    if (va) add_entry(ea, wa);
+    if (m + 2 < M) va = obs(m + 2, ea, wa);
+    if (vb) add_entry(eb, wb);
   }
-  if (m < M) add_entry(ea, wa);
+  if (m < M && va) add_entry(ea, wa);
 
   // --- control cost (I/Constraints.cpp:110-131)
   const double e1 = exp_fast(kp.q2_acc * (u0 - kp.acc_max));

@@ -66,11 +66,12 @@ struct TabObstacles {  // obstacle accessor over the [m][t][field] table (LDS or
   double w_default;
   // An entry is 48 contiguous bytes, read as three 16-byte accesses.  In LDS the lane stride of 12 dwords makes each
   // quarter-wave's b128 reads cover all 64 banks exactly once (12·i mod 64, i < 16, are 16 distinct multiples of 4).
-  __device__ __forceinline__ void operator()(int m, ObsEntry& e, double& w) const {
+  __device__ __forceinline__ bool operator()(int m, ObsEntry& e, double& w) const {
     const double2* p = reinterpret_cast<const double2*>(tab + (size_t)m * TABF * N);
     const double2 a = p[0], b = p[1], c = p[2];
     e.ox = a.x; e.oy = a.y; e.co = b.x; e.so = b.y; e.ia2 = c.x; e.ib2 = c.y;
     w = wts ? wts[m] : w_default;
+    return true;
   }
 };
 
@@ -96,6 +97,9 @@ struct SampledObstacles {
   int N, S, n_obs;
   double w;
   int o, s;
+  bool far;                                // the obstacle in use is negligible at every step of this wavefront (see below)
+  const double* rmax;                      // LDS [o]: largest |(dx, dy)| over the obstacle's samples
+  double fx, fy, rx, ry, kf, kr;           // this step's two ego circle centres; sqrt(1 + 64/q2) for either circle
   double x, y, c0, s0, vt, ha, hb;         // nominal record in use
   double nx, ny, nc0, ns0, nvt, nha, nhb;  // the next obstacle's, requested one obstacle (S entries) ahead
   __device__ __forceinline__ void request(int oo) {
@@ -103,11 +107,25 @@ struct SampledObstacles {
     const double2 a = p[0], b = p[1], c = p[2], d = p[3];
     nx = a.x; ny = a.y; nc0 = b.x; ns0 = b.y; nvt = c.x; nha = c.y; nhb = d.x;
   }
-  // called with m = 0, 1, 2, … in order (lin_step does)
-  __device__ __forceinline__ void operator()(int, ObsEntry& e, double& wout) {
+  // called with m = 0, 1, 2, … in order (lin_step does); false: the entry is negligible, nothing was written
+  __device__ __forceinline__ bool operator()(int, ObsEntry& e, double& wout) {
     if (s == 0) {
       x = nx; y = ny; c0 = nc0; s0 = ns0; vt = nvt; ha = nha; hb = nhb;
       if (o + 1 < n_obs) request(o + 1);
+      // Whole-obstacle test before any per-sample work.  Every sample's centre is within R = rmax[o] of the nominal one
+      // and both its semi-axes are at most A = max(ha, hb) + |vt| whatever its heading, so d'Pd ≥ ((D - R)/A)² for an ego
+      // circle at distance D from the nominal centre; q2·(1 - d'Pd) ≤ -64 follows from D ≥ R + A·sqrt(1 + 64/q2).  If that
+      // holds for both circles at every step of the wavefront, the obstacle's samples are all below lin_step's own
+      // threshold: skipped here for the price of this test instead of 46 instructions per sample.
+      const double A = fmax(ha, hb) + fabs(vt), R = rmax[o];
+      const double df = (fx - x) * (fx - x) + (fy - y) * (fy - y), dr = (rx - x) * (rx - x) + (ry - y) * (ry - y);
+      const double tf = (R + A * kf) * (1.0 + 1.0e-9), tr = (R + A * kr) * (1.0 + 1.0e-9);
+      const bool is_far = df >= tf * tf && dr >= tr * tr;  // false for NaN
+      far = __builtin_amdgcn_ballot_w64(!is_far) == 0;
+    }
+    if (far) {
+      if (++s == S) { s = 0; ++o; }
+      return false;
     }
     const double2* q = reinterpret_cast<const double2*>(off + ((size_t)o * S + s) * OFFF);
     const double2 d = q[0], r = q[1];
@@ -120,17 +138,24 @@ struct SampledObstacles {
     e.oy = y + d.y;
     wout = w;
     if (++s == S) { s = 0; ++o; }
+    return true;
   }
 };
 struct SampledSource {
   const double* nom;
   const double* off;
+  const double* rmax;
+  const double* X;  // LDS trajectory (XR doubles per step)
   int N, S, n_obs;
-  double w;
+  double w, ego_front, ego_rear, kf, kr;
   __device__ __forceinline__ SampledObstacles at(int t) const {
     SampledObstacles a;
     a.nom = nom + (size_t)t * NOMF; a.off = off; a.N = N; a.S = S; a.n_obs = n_obs; a.w = w;
-    a.o = 0; a.s = 0;
+    a.o = 0; a.s = 0; a.far = false; a.rmax = rmax;
+    const double* xr = X + t * XR;
+    a.fx = xr[0] + xr[4] * ego_front; a.fy = xr[1] + xr[5] * ego_front;
+    a.rx = xr[0] - xr[4] * ego_rear; a.ry = xr[1] - xr[5] * ego_rear;
+    a.kf = kf; a.kr = kr;
     a.request(0);
     return a;
   }
@@ -335,7 +360,8 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   double* rec = Ub + 2 * N;
   double* kK = rec + N * REC;
   double* tab = TAB == 1 ? kK + N * KR : a.obs_tab + (size_t)b * M * (TAB == 2 ? NOMF : TABF) * N;
-  double* off = kK + N * KR;  // TAB == 2: offset records [o][s][OFFF]
+  double* off = kK + N * KR;  // TAB == 2: offset records [o][s][OFFF], then rmax[o]
+  double* rmax = off + (size_t)M * a.n_samples * OFFF;
 
   // ---- prologue -------------------------------------------------------------------------------------------
   SampleGrid grid;
@@ -369,6 +395,15 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
       sincos(q[2], &sn, &cs);
       double* o = off + (size_t)i * OFFF;
       o[0] = q[0]; o[1] = q[1]; o[2] = cs; o[3] = sn;
+    }
+    for (int o = lane; o < M; o += WAVE) {  // largest sample displacement per obstacle (SampledObstacles' whole-obstacle test)
+      double r2 = 0.0;
+      for (int q = 0; q < a.n_samples; ++q) {
+        const double* f = a.samp_off + ((size_t)b * n_off + (size_t)o * a.n_samples + q) * 3;
+        const double d2 = f[0] * f[0] + f[1] * f[1];
+        r2 = fmax(r2, d2 == d2 ? d2 : __builtin_huge_val());
+      }
+      rmax[o] = sqrt(r2);
     }
   } else {
     for (int m = 0; m < M; ++m) {  // obstacle table, I/Obstacle.cpp:41-62
@@ -423,7 +458,8 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
     {
       double part;
       const KParams kpl = phase_params();  // phase-local read of the parameter block (cilqr_device.hpp)
-      if (TAB == 2) part = linearize(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, SampledSource{tab, off, N, a.n_samples, M, a.samp_w});
+      if (TAB == 2) part = linearize(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, SampledSource{tab, off, rmax, Xc, N, a.n_samples, M, a.samp_w, kpl.ego_front, kpl.ego_rear,
+                                                     sqrt(1.0 + 64.0 / kpl.q2_front), sqrt(1.0 + 64.0 / kpl.q2_rear)});
       else part = linearize(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, TabSource{tab, wts, N, kpl.w_obstacle});
       J_new = readfirstlane_f64(wave_sum(part));
     }
@@ -537,7 +573,9 @@ size_t solve_lds_bytes(int N, int n_samples) {
   return doubles * sizeof(double);
 }
 
-size_t solve_sampled_lds_bytes(int n_obs, int n_samples) { return (size_t)n_obs * n_samples * OFFF * sizeof(double); }
+size_t solve_sampled_lds_bytes(int n_obs, int n_samples) {
+  return ((size_t)n_obs * n_samples * OFFF + (size_t)n_obs) * sizeof(double);  // offset records + rmax
+}
 size_t solve_sampled_tab_doubles(int n_obs, int N) { return (size_t)n_obs * NOMF * N; }
 
 hipError_t launch_quu_inverse(int n, const double* q, const double* lamb, double* out, int general, hipStream_t stream) {

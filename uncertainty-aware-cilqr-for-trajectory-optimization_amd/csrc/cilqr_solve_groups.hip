@@ -254,6 +254,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
           const double2 q0 = p[0], q1 = p[1], q2 = p[2];
           e.ox = q0.x; e.oy = q0.y; e.co = q1.x; e.so = q1.y; e.ia2 = q2.x; e.ib2 = q2.y;
           w = wts ? wts[m] : kpl.w_obstacle;
+          return true;
         };
         Rec c;
         Jpart += lin_step(kpl, cur.px, cur.py, cur.v, cur.ct, cur.st, cur.u0, cur.u1, cur.vn, cur.cn, cur.sn, cx, cy, M, obs, c);
