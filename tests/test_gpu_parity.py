@@ -294,7 +294,8 @@ def test_grouped_kernels_match_oracle(cilqr, oracle, G):
     finally:
         del os.environ["CILQR_FORCE_G"]
     try:
-        for N, M, B, seed in ((50, 4, 203, 301), (80, 16, 37, 302), (50, 0, 65, 303), (7, 2, 5, 304)):
+        for N, M, B, seed in ((50, 4, 203, 301), (80, 16, 37, 302), (50, 0, 65, 303), (7, 2, 5, 304), (1, 1, 9, 305), (2, 0, 3, 306),
+                              (3, 2, 4, 307)):
             sc = scenes.make_static(B, N, M, cilqr.default_params(N), seed)
             _compare(_gpu_batch(s, sc), _oracle_batch(oracle, N, sc), TIGHT, "G%d N%d M%d" % (G, N, M))
         # hand-over to the GENERAL instantiation (huge heading) and the NaN containment, as for the wavefront family
@@ -821,3 +822,22 @@ def test_closest_point_windows_on_steep_and_distant_paths(cilqr, oracle, G, monk
     ok = np.isfinite(want["U"]).all(axis=1)
     assert ok.sum() >= B * 0.9
     _compare({k: v[ok] for k, v in got.items()}, {k: v[ok] for k, v in want.items()}, 1e-8, "closest-point windows G=%d" % G)
+
+
+@pytest.mark.parametrize("G", [1, 8, 32])
+def test_early_exit_equals_reference_loop_grouped_family(cilqr, monkeypatch, G):
+    """The same equivalence for the G-lanes-per-solve family: stopping at the first rejection and replaying the λ / counter
+    arithmetic gives bit for bit what executing the rejected iterations' passes gives.  (With the flag, a solve that has
+    rejected stops swapping its trajectory buffers while its neighbours in the wavefront go on: the forward pass must then
+    read each group's own buffer — this test found the staged copy using one source for the whole wavefront.)"""
+    from cilqr_amd import scenes
+    monkeypatch.setenv("CILQR_FORCE_G", str(G))
+    p = cilqr.default_params(50)
+    sc = scenes.make_static(200, 50, 4, p, 515)
+    s = cilqr.Solver(p, max_batch=200, max_horizon=50, max_obstacles=4, device=0)
+    try:
+        a, b = _gpu_batch(s, sc), _gpu_batch(s, sc, flags=cilqr.FLAG_FAITHFUL_ITERS)
+    finally:
+        s.close()
+    for k in ("U", "X", "J", "iters", "status"):
+        assert np.array_equal(a[k], b[k]), k

@@ -398,44 +398,60 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
           if (g == 0) { double* ur = &UF(un, i, 0); ur[0] = u0; ur[S] = u1; }
           store_state(xn, i + 1, s);
         };
-        // chunks of `chunk` steps, oldest first: X rows, U rows and gain rows of a chunk side by side in a staging buffer
-        const double* wave_ws = ws_base + (size_t)blockIdx.x * L.rows() * S;
-        const int buf_doubles = chunk * STAGE_ROWS * S;
-        auto copy_chunk = [&](int lo, int hi, double* dst) {
-          const int n = hi - lo + 1;
-          stage_copy(wave_ws + (size_t)(xc + lo * XR) * S, dst, n * XR * S);
-          stage_copy(wave_ws + (size_t)(uc + lo * 2) * S, dst + chunk * XR * S, n * 2 * S);
-          stage_copy(wave_ws + (size_t)(L.kk() + lo * KR) * S, dst + chunk * (XR + 2) * S, n * KR * S);
-        };
-        auto lds_fwd = [&](FwdIn& o, const double* base, int t_rel) {
-          const double* xr = base + (size_t)t_rel * XR * S + grp;
-          const double* ur = base + (size_t)(chunk * XR + t_rel * 2) * S + grp;
-          const double* kr = base + (size_t)(chunk * (XR + 2) + t_rel * KR) * S + grp;
-          o.x = xr[0]; o.y = xr[S]; o.v = xr[2 * S]; o.th = xr[3 * S];
-          o.u0 = ur[0]; o.u1 = ur[S];
-#pragma unroll
-          for (int q = 0; q < KR; ++q) o.g[q] = kr[q * S];
-        };
-        int lo = 0, hi = chunk - 1 < N - 1 ? chunk - 1 : N - 1, buf = 0;
-        copy_chunk(lo, hi, stage);
-        stage_wait();
-        while (lo < N) {
-          const int nlo = hi + 1, nhi = nlo + chunk - 1 < N - 1 ? nlo + chunk - 1 : N - 1;
-          if (nlo < N) copy_chunk(nlo, nhi, stage + (buf ^ 1) * buf_doubles);
-          const double* cur = stage + buf * buf_doubles;
-          int i = lo;
-          lds_fwd(fa, cur, 0);
-          for (; i + 1 <= hi; i += 2) {
-            lds_fwd(fb, cur, i + 1 - lo);
+        if (faithful) {
+          // With CILQR_FLAG_FAITHFUL_ITERS a solve that has rejected keeps iterating without swapping its trajectory
+          // buffers while its neighbours in the wavefront go on swapping theirs, so the groups no longer agree on which
+          // buffer is current and the whole-wavefront chunk copy below (one source address for all) does not apply:
+          // operands come straight from each group's own rows, one step ahead.
+          load_fwd(fa, 0);
+          int i = 0;
+          for (; i + 1 < N; i += 2) {
+            load_fwd(fb, i + 1);
             step(fa, i);
-            lds_fwd(fa, cur, i + 2 <= hi ? i + 2 - lo : 0);
+            load_fwd(fa, i + 2 < N ? i + 2 : i + 1);
             step(fb, i + 1);
           }
-          if (i == hi) step(fa, hi);
+          if (i < N) step(fa, i);
+        } else {
+          // chunks of `chunk` steps, oldest first: X rows, U rows and gain rows of a chunk side by side in a staging buffer
+          const double* wave_ws = ws_base + (size_t)blockIdx.x * L.rows() * S;
+          const int buf_doubles = chunk * STAGE_ROWS * S;
+          auto copy_chunk = [&](int lo, int hi, double* dst) {
+            const int n = hi - lo + 1;
+            stage_copy(wave_ws + (size_t)(xc + lo * XR) * S, dst, n * XR * S);
+            stage_copy(wave_ws + (size_t)(uc + lo * 2) * S, dst + chunk * XR * S, n * 2 * S);
+            stage_copy(wave_ws + (size_t)(L.kk() + lo * KR) * S, dst + chunk * (XR + 2) * S, n * KR * S);
+          };
+          auto lds_fwd = [&](FwdIn& o, const double* base, int t_rel) {
+            const double* xr = base + (size_t)t_rel * XR * S + grp;
+            const double* ur = base + (size_t)(chunk * XR + t_rel * 2) * S + grp;
+            const double* kr = base + (size_t)(chunk * (XR + 2) + t_rel * KR) * S + grp;
+            o.x = xr[0]; o.y = xr[S]; o.v = xr[2 * S]; o.th = xr[3 * S];
+            o.u0 = ur[0]; o.u1 = ur[S];
+  #pragma unroll
+            for (int q = 0; q < KR; ++q) o.g[q] = kr[q * S];
+          };
+          int lo = 0, hi = chunk - 1 < N - 1 ? chunk - 1 : N - 1, buf = 0;
+          copy_chunk(lo, hi, stage);
           stage_wait();
-          lo = nlo;
-          hi = nhi;
-          buf ^= 1;
+          while (lo < N) {
+            const int nlo = hi + 1, nhi = nlo + chunk - 1 < N - 1 ? nlo + chunk - 1 : N - 1;
+            if (nlo < N) copy_chunk(nlo, nhi, stage + (buf ^ 1) * buf_doubles);
+            const double* cur = stage + buf * buf_doubles;
+            int i = lo;
+            lds_fwd(fa, cur, 0);
+            for (; i + 1 <= hi; i += 2) {
+              lds_fwd(fb, cur, i + 1 - lo);
+              step(fa, i);
+              lds_fwd(fa, cur, i + 2 <= hi ? i + 2 - lo : 0);
+              step(fb, i + 1);
+            }
+            if (i == hi) step(fa, hi);
+            stage_wait();
+            lo = nlo;
+            hi = nhi;
+            buf ^= 1;
+          }
         }
         if (!(max_th < 1.0e6)) { handover = true; break; }
       }
