@@ -188,7 +188,10 @@ int cilqr_solve_batch(cilqr_handle* h, int B, int N, int M,
                       uint32_t flags);
 
 /* Same, with every pointer a DEVICE pointer on the handle's device and the work enqueued on `stream`
- * (a hipStream_t passed as void*; NULL = the HIP null stream, as everywhere in HIP).  Asynchronous: returns after launch. */
+ * (a hipStream_t passed as void*; NULL = the HIP null stream, as everywhere in HIP).  Asynchronous: returns after launch.
+ * The handle's device workspaces (obstacle table, grouped-family arrays, hand-over flags) serve ONE solve at a time: calls
+ * enqueued on the same stream follow each other and are fine; solves that may overlap in time on different streams need
+ * different handles. */
 int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
                              const double* x0, double* U, const double* poly, const double* xplan_fl,
                              const double* obs_pose, const double* obs_dim, const double* obs_weight,

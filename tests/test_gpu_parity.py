@@ -841,3 +841,56 @@ def test_early_exit_equals_reference_loop_grouped_family(cilqr, monkeypatch, G):
         s.close()
     for k in ("U", "X", "J", "iters", "status"):
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_device_pointer_entry_points_on_a_side_stream(cilqr):
+    """The *_device entry points (device pointers, caller's stream, asynchronous) give bit for bit what the host-buffer entry
+    points give: plain solve, sampled solve (also under FAITHFUL_ITERS) and the batched LocalPlanner, enqueued back to
+    back on a non-default stream with a single synchronisation at the end."""
+    import torch
+    from cilqr_amd import scenes
+    dev = torch.device("cuda", 0)
+    N, B = 50, 96
+    p = cilqr.default_params(N)
+    sc = scenes.make_c3(B, p, n_dyn=4, n_samples=8)
+    M = sc["M"]
+    s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M, device=0)
+    try:
+        host_plain = s.solve_batch(N, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"], sc["obs_weight"])
+        host_samp = s.solve_batch_sampled(N, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["nom_pose"], sc["nom_dim"],
+                                          sc["offsets"], sc["sample_weight"])
+        i = np.arange(200.0)
+        path = np.stack([i, 0.5 * np.sin(0.05 * i)], axis=1)
+        egos = np.stack([np.linspace(0, 150, B), 0.5 * np.sin(0.05 * np.linspace(0, 150, B)) + 0.2, np.full(B, 3.0), np.zeros(B)], axis=1)
+        host_plan = s.local_plan_batch(path, egos)
+
+        t = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)  # noqa: E731
+        d = {k: t(sc[k]) for k in ("x0", "poly", "xplan_fl", "obs_pose", "obs_dim", "obs_weight", "nom_pose", "nom_dim", "offsets")}
+        U1, U2, U3 = t(sc["U"]), t(sc["U"]), t(sc["U"])
+        outs = [dict(X=torch.zeros(B, 4 * (N + 1), dtype=torch.float64, device=dev), J=torch.zeros(B, dtype=torch.float64, device=dev),
+                     it=torch.zeros(B, dtype=torch.int32, device=dev), st=torch.zeros(B, dtype=torch.int32, device=dev)) for _ in range(3)]
+        d_path, d_ego = t(path), t(egos)
+        d_poly = torch.zeros(B, 6, dtype=torch.float64, device=dev)
+        d_fl = torch.zeros(B, 2, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            st_ = side.cuda_stream
+            o = outs[0]
+            s.solve_batch_device(st_, B, N, M, d["x0"].data_ptr(), U1.data_ptr(), d["poly"].data_ptr(), d["xplan_fl"].data_ptr(),
+                                 d["obs_pose"].data_ptr(), d["obs_dim"].data_ptr(), d["obs_weight"].data_ptr(), o["X"].data_ptr(),
+                                 o["J"].data_ptr(), o["it"].data_ptr(), o["st"].data_ptr())
+            for o, U, fl in ((outs[1], U2, 0), (outs[2], U3, cilqr.FLAG_FAITHFUL_ITERS)):
+                s.solve_batch_sampled_device(st_, B, N, 4, 8, d["x0"].data_ptr(), U.data_ptr(), d["poly"].data_ptr(),
+                                             d["xplan_fl"].data_ptr(), d["nom_pose"].data_ptr(), d["nom_dim"].data_ptr(),
+                                             d["offsets"].data_ptr(), sc["sample_weight"], o["X"].data_ptr(), o["J"].data_ptr(),
+                                             o["it"].data_ptr(), o["st"].data_ptr(), flags=fl)
+            s.local_plan_batch_device(st_, B, 200, d_path.data_ptr(), 0, d_ego.data_ptr(), d_poly.data_ptr(), d_fl.data_ptr())
+        side.synchronize()
+    finally:
+        s.close()
+    for o, U, want in ((outs[0], U1, host_plain), (outs[1], U2, host_samp), (outs[2], U3, host_samp)):
+        assert np.array_equal(U.cpu().numpy(), want["U"])
+        assert np.array_equal(o["X"].cpu().numpy(), want["X"]) and np.array_equal(o["J"].cpu().numpy(), want["J"])
+        assert np.array_equal(o["it"].cpu().numpy(), want["iters"]) and np.array_equal(o["st"].cpu().numpy(), want["status"])
+    assert np.array_equal(d_poly.cpu().numpy(), host_plan["poly"]) and np.array_equal(d_fl.cpu().numpy(), host_plan["xplan_fl"])
