@@ -312,6 +312,18 @@ def test_grouped_kernels_match_oracle(cilqr, oracle, G):
         # sampled, weighted obstacles (config-3 shape)
         sc3 = scenes.make_c3(24, cilqr.default_params(50), n_dyn=4, n_samples=4)
         _compare(_gpu_batch(s, sc3), _oracle_batch(oracle, 50, sc3), TIGHT, "G%d C3" % G)
+        # more obstacles than the 64-bit held-row mask covers (the 6 beyond it are streamed), all of them constant over the horizon
+        s.close()
+        os.environ["CILQR_FORCE_G"] = str(G)
+        try:
+            s = cilqr.Solver(cilqr.default_params(), max_batch=16, max_horizon=150, max_obstacles=70, device=0)
+        finally:
+            del os.environ["CILQR_FORCE_G"]
+        sc70 = scenes.make_static(7, 20, 70, cilqr.default_params(20), 308)
+        _compare(_gpu_batch(s, sc70), _oracle_batch(oracle, 20, sc70), TIGHT, "G%d M70" % G)
+        # a horizon of many staging chunks, not a multiple of the chunk length
+        sc150 = scenes.make_static(6, 150, 2, cilqr.default_params(150), 309)
+        _compare(_gpu_batch(s, sc150), _oracle_batch(oracle, 150, sc150), 1e-8, "G%d N150" % G)
     finally:
         s.close()
 
