@@ -906,3 +906,20 @@ def test_device_pointer_entry_points_on_a_side_stream(cilqr):
         assert np.array_equal(o["X"].cpu().numpy(), want["X"]) and np.array_equal(o["J"].cpu().numpy(), want["J"])
         assert np.array_equal(o["it"].cpu().numpy(), want["iters"]) and np.array_equal(o["st"].cpu().numpy(), want["status"])
     assert np.array_equal(d_poly.cpu().numpy(), host_plan["poly"]) and np.array_equal(d_fl.cpu().numpy(), host_plan["xplan_fl"])
+
+
+def test_occupancy_conversion_odd_ranges_large_grid(cilqr, oracle, solver):
+    """Ranges for which the step-table path must stand aside (reversed, empty, denormal, infinite or NaN bounds) and ordinary
+    ones, on a grid large enough (2^20 cells) for that path to be considered: always the oracle's bytes."""
+    rng = np.random.default_rng(21)
+    n = 1 << 20
+    vals = rng.uniform(-50, 150, n).astype(np.float32)
+    vals[rng.integers(0, n, 5000)] = np.nan
+    vals[rng.integers(0, n, 3000)] = np.float32(np.inf)
+    vals[rng.integers(0, n, 3000)] = np.float32(-np.inf)
+    vals[:101] = np.arange(101, dtype=np.float32)
+    for lo, hi in ((0.0, 100.0), (100.0, 0.0), (7.0, 7.0), (0.0, 1e-40), (0.0, np.inf), (-np.inf, 0.0), (np.nan, 1.0), (0.0, np.nan),
+                   (-3.0e38, 3.0e38), (1e-3, 2e-3), (-1.0, 100.0)):
+        got = solver.layer_to_occupancy(vals, lo, hi)
+        want = oracle.layer_to_occupancy(vals, lo, hi)
+        assert np.array_equal(got, want), (lo, hi, int((got != want).sum()))
