@@ -923,3 +923,31 @@ def test_occupancy_conversion_odd_ranges_large_grid(cilqr, oracle, solver):
         got = solver.layer_to_occupancy(vals, lo, hi)
         want = oracle.layer_to_occupancy(vals, lo, hi)
         assert np.array_equal(got, want), (lo, hi, int((got != want).sum()))
+
+
+def test_local_plan_batch_other_slice_length(cilqr, oracle):
+    """num_of_local_wpts ≠ 20 takes the plain-loop instantiation of the fit kernel (and changes the solver's path-sample
+    count to 10 × that): fit and a plan + solve against the oracle with num_of_local_wpts = 12."""
+    from cilqr_amd import scenes
+    N, B = 40, 64
+    p = cilqr.default_params(N)
+    p.num_of_local_wpts = 12
+    po = oracle.default_params(N)
+    po.num_of_local_wpts = 12
+    i = np.arange(120.0)
+    path = np.stack([i, 0.8 * np.sin(0.04 * i)], axis=1)
+    rng = np.random.default_rng(31)
+    along = rng.uniform(0, 118, B)
+    egos = np.stack([along, 0.8 * np.sin(0.04 * along) + rng.uniform(-0.5, 0.5, B), rng.uniform(1, 6, B), rng.uniform(-0.1, 0.1, B)], axis=1)
+    s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=0, device=0)
+    try:
+        plan = s.local_plan_batch(path, egos)
+        got = s.solve_batch(N, egos, np.tile(cilqr.default_control_seq(N), (B, 1)), plan["poly"], plan["xplan_fl"])
+    finally:
+        s.close()
+    poly, fl, n, refs = _oracle_plans(oracle, po, path, egos)
+    assert np.array_equal(plan["n"], n) and n.max() == 12
+    assert np.array_equal(plan["poly"], poly) and np.array_equal(plan["xplan_fl"], fl)  # integer abscissae: exact powers
+    want = oracle.solve_batch(po, N, 0, egos, np.tile(cilqr.default_control_seq(N), (B, 1)), poly, fl, None, None, None,
+                              threads=min(16, oracle.max_threads()))
+    _compare(got, want, TIGHT, "12 waypoints")
