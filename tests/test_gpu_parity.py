@@ -951,3 +951,42 @@ def test_local_plan_batch_other_slice_length(cilqr, oracle):
     want = oracle.solve_batch(po, N, 0, egos, np.tile(cilqr.default_control_seq(N), (B, 1)), poly, fl, None, None, None,
                               threads=min(16, oracle.max_threads()))
     _compare(got, want, TIGHT, "12 waypoints")
+
+
+@pytest.mark.parametrize("G", [0, 8])
+def test_non_default_parameters(cilqr, oracle, G, monkeypatch):
+    """Every field of cilqr_params reaches the kernels: short iteration caps, a loose tolerance (exit by tolerance, status 0),
+    other weights, barrier constants, limits, margins, timestep and regularisation schedule — both kernel families."""
+    from cilqr_amd import scenes
+    if G:
+        monkeypatch.setenv("CILQR_FORCE_G", str(G))
+    N, M, B = 40, 3, 96
+    variants = [
+        dict(max_iterations=6),
+        dict(tolerance=0.5),
+        dict(max_iterations=33, lamb_factor=4.0, lamb_max=300.0),
+        dict(w_acc=2.0, w_yawrate=1.5, w_pos=1.1, w_vel=0.7, w_obstacle=0.6, desired_speed=7.5),
+        dict(q1_acc=0.7, q2_acc=1.3, q1_yawrate=1.2, q2_yawrate=0.8, q1_front=2.0, q2_front=2.2, q1_rear=3.0, q2_rear=1.9),
+        dict(acc_max=1.2, acc_min=-3.0, steer_angle_max=0.5, steer_angle_min=-0.4, wheelbase=2.5, speed_max=12.0),
+        dict(t_safe=0.4, s_safe_a=0.3, s_safe_b=0.2, ego_rad=1.1, ego_front=1.8, ego_rear=2.1, timestep=0.07),
+    ]
+    saw_tolerance_exit = False
+    for k, v in enumerate(variants):
+        p, po = cilqr.default_params(N), oracle.default_params(N)
+        for name, val in v.items():
+            assert hasattr(p, name) and hasattr(po, name), name
+            setattr(p, name, val)
+            setattr(po, name, val)
+        sc = scenes.make_static(B, N, M, p, 700 + k)
+        s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M, device=0)
+        try:
+            got = _gpu_batch(s, sc)
+        finally:
+            s.close()
+        want = oracle.solve_batch(po, N, M, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"], None,
+                                  threads=min(16, oracle.max_threads()))
+        _compare(got, want, 1e-8, "variant %d G=%d" % (k, G))
+        saw_tolerance_exit |= bool((want["status"] == 0).any())
+        if "max_iterations" in v:
+            assert want["iters"].max() <= v["max_iterations"]
+    assert saw_tolerance_exit
