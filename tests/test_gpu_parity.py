@@ -221,7 +221,18 @@ def test_cpp_adapter_replays_reference_call_sequence(cilqr, oracle, tmp_path):
     assert t1["iterations"] == o1["iters"] and t1["exit"] == o1["status"]
     assert np.max(np.abs(np.array(t1["U"]) - o1["U"])) < 1e-8
     assert t0["n_ref"] == 20
-    assert 0 <= out["best"] < 8 and np.isfinite(out["best_J"])
+    # run_candidates: eight perturbed ego states from the warm start left by tick 2, one launch, minimum-cost pick — against
+    # the oracle's eight pre-steps + solves and its strict-< first minimum
+    i = np.arange(200.0)
+    path = np.stack([i, 0.5 * np.sin(0.05 * i)], axis=1)
+    Js = []
+    for c in range(8):
+        ego = np.array([0.05 * c, 0.1 - 0.04 * c, 3.0, 0.02 + 0.01 * c])
+        coeffs, ref = oracle.local_plan(po, path, ego)
+        r = oracle.solve(po, 50, ego, o1["U"], coeffs, ref[0, 0], ref[-1, 0], sc["obs_pose"][0], sc["obs_dim"][0])
+        Js.append(r["J"])
+    assert out["best"] == int(np.argmin(Js))
+    assert abs(out["best_J"] - min(Js)) < 1e-9 * max(1.0, abs(min(Js)))
 
 
 # ------------------------------------------------------------------------------------------------ rare branches
@@ -990,3 +1001,42 @@ def test_non_default_parameters(cilqr, oracle, G, monkeypatch):
         if "max_iterations" in v:
             assert want["iters"].max() <= v["max_iterations"]
     assert saw_tolerance_exit
+
+
+def test_two_handles_overlapping_on_two_streams(cilqr):
+    """Solves that overlap in time need separate handles (include/cilqr.h): two handles, two streams, launches interleaved
+    without synchronising in between — each must give what it gives alone."""
+    import torch
+    from cilqr_amd import scenes
+    dev = torch.device("cuda", 0)
+    N, M, B = 50, 4, 512
+    p = cilqr.default_params(N)
+    scs = [scenes.make_static(B, N, M, p, 900 + k) for k in range(2)]
+    solvers = [cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M, device=0) for _ in range(2)]
+    try:
+        alone = [s.solve_batch(N, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"]) for s, sc in zip(solvers, scs)]
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        dv = [{k: t(sc[k]) for k in ("x0", "U", "poly", "xplan_fl", "obs_pose", "obs_dim")} for sc in scs]
+        X = [torch.zeros(B, 4 * (N + 1), dtype=torch.float64, device=dev) for _ in range(2)]
+        J = [torch.zeros(B, dtype=torch.float64, device=dev) for _ in range(2)]
+        it = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
+        st = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
+        U0 = [d["U"].clone() for d in dv]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for rep in range(3):  # the same solve three times per handle, streams interleaved
+            for k in range(2):
+                with torch.cuda.stream(streams[k]):
+                    dv[k]["U"].copy_(U0[k])
+                    solvers[k].solve_batch_device(streams[k].cuda_stream, B, N, M, dv[k]["x0"].data_ptr(), dv[k]["U"].data_ptr(),
+                                                  dv[k]["poly"].data_ptr(), dv[k]["xplan_fl"].data_ptr(), dv[k]["obs_pose"].data_ptr(),
+                                                  dv[k]["obs_dim"].data_ptr(), 0, X[k].data_ptr(), J[k].data_ptr(), it[k].data_ptr(),
+                                                  st[k].data_ptr())
+        for s_ in streams:
+            s_.synchronize()
+    finally:
+        for s in solvers:
+            s.close()
+    for k in range(2):
+        assert np.array_equal(dv[k]["U"].cpu().numpy(), alone[k]["U"]) and np.array_equal(X[k].cpu().numpy(), alone[k]["X"])
+        assert np.array_equal(it[k].cpu().numpy(), alone[k]["iters"]) and np.array_equal(st[k].cpu().numpy(), alone[k]["status"])
