@@ -114,3 +114,23 @@ def test_product_does_not_reference_oracle():
             text = open(os.path.join(dirpath, f), errors="ignore").read()
             hit = re.search(r"(from|import)\s+oracle|oracle\s*[/.]|liboracle|cilqr_oracle|_ref/", text)
             assert hit is None, (os.path.join(dirpath, f), hit.group(0))
+
+
+def test_replay_tool_fails_loudly_without_a_device(cilqr, tmp_path):
+    """bin/cilqr_replay on a box without a GPU: a message and exit code 1 — no CPU path, no crash."""
+    import os
+    import subprocess
+    from conftest import PKG
+    exe = os.path.join(PKG, "bin", "cilqr_replay")
+    assert os.path.exists(exe), "bin/cilqr_replay not built"
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is present")
+    except ImportError:
+        pass
+    log = tmp_path / "one_tick.log"
+    log.write_text("cilqr-replay 1\nhorizon 10\npath 3\n0 0\n1 0\n2 0\ntick\nego 0 0 1 0\nobstacles 0\n")
+    p = subprocess.run([exe, str(log)], capture_output=True, text=True)
+    assert p.returncode == 1 and p.stdout == ""
+    assert "device" in p.stderr.lower() or "hip" in p.stderr.lower()
