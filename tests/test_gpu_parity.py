@@ -1040,3 +1040,24 @@ def test_two_handles_overlapping_on_two_streams(cilqr):
     for k in range(2):
         assert np.array_equal(dv[k]["U"].cpu().numpy(), alone[k]["U"]) and np.array_equal(X[k].cpu().numpy(), alone[k]["X"])
         assert np.array_equal(it[k].cpu().numpy(), alone[k]["iters"]) and np.array_equal(st[k].cpu().numpy(), alone[k]["status"])
+
+
+def test_local_plan_batch_tiny_paths(cilqr, oracle, solver):
+    """Paths of 1, 2, 3 and 7 waypoints (fewer rows than the six unknowns, down to a single row), one candidate or several,
+    shared or per-candidate paths: slice, coefficients and fitted reference against the oracle (integer abscissae: exact)."""
+    p = oracle.default_params(50)
+    rng = np.random.default_rng(41)
+    for P in (1, 2, 3, 7):
+        for B in (1, 5):
+            x = np.arange(P, dtype=float) + 3.0
+            path = np.stack([x, 0.25 * x - 1.0 + 0.1 * np.sin(x)], axis=1)
+            egos = np.stack([rng.uniform(2, 3 + P, B), rng.uniform(-1, 1, B), np.full(B, 2.0), np.zeros(B)], axis=1)
+            got = solver.local_plan_batch(path, egos)
+            poly, fl, n, refs = _oracle_plans(oracle, p, path, egos)
+            assert np.array_equal(got["n"], n) and np.array_equal(got["xplan_fl"], fl), (P, B)
+            assert np.array_equal(got["poly"], poly), (P, B)
+            for b in range(B):
+                assert np.array_equal(got["ref_traj"][b, :n[b]], refs[b]), (P, B, b)
+            per = np.broadcast_to(path, (B, P, 2)).copy()
+            got2 = solver.local_plan_batch(per, egos)
+            assert np.array_equal(got2["poly"], poly) and np.array_equal(got2["n"], n), (P, B)
