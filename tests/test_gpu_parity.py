@@ -1061,3 +1061,31 @@ def test_local_plan_batch_tiny_paths(cilqr, oracle, solver):
             per = np.broadcast_to(path, (B, P, 2)).copy()
             got2 = solver.local_plan_batch(per, egos)
             assert np.array_equal(got2["poly"], poly) and np.array_equal(got2["n"], n), (P, B)
+
+
+def test_costmap_kernels_on_tiny_and_odd_maps(cilqr, oracle, solver):
+    """Warp, blur and conversions on maps of 1x1, 3x2, 65x17 cells (tiles, wavefronts and the conversions' 4-cell groups all
+    partially filled) and a destination mostly outside its source: every output and every out-of-range count as the oracle."""
+    rng = np.random.default_rng(51)
+    for (slx, sly, sres), (dlx, dly, dres, dpx, dpy), pose in [
+            ((1.0, 1.0, 1.0), (1.0, 1.0, 1.0, 0.0, 0.0), (0.1, -0.1, 0.3)),
+            ((3.0, 2.0, 1.0), (3.0, 2.0, 1.0, 0.0, 0.0), (0.0, 0.0, 0.0)),
+            ((13.0, 3.4, 0.2), (6.5, 1.7, 0.1, 0.3, -0.2), (0.4, 0.1, 2.0)),
+            ((4.0, 4.0, 0.5), (20.0, 12.0, 0.5, 1.0, 1.0), (0.5, 0.5, 0.7))]:   # destination far larger than the source
+        sg, dg = cilqr.map_geom(slx, sly, sres, 0.5, -0.5), cilqr.map_geom(dlx, dly, dres, dpx, dpy)
+        osg, odg = oracle.map_geom(slx, sly, sres, 0.5, -0.5), oracle.map_geom(dlx, dly, dres, dpx, dpy)
+        src = np.asfortranarray(rng.integers(0, 101, (sg.rows, sg.cols)).astype(np.float32))
+        if src.size > 4:
+            src[rng.random(src.shape) < 0.1] = np.nan
+        got, n_oob = solver.warp_costmap(src, sg, dg, *pose)
+        want, w_oob = oracle.warp(src, osg, odg, *pose)
+        assert n_oob == w_oob and np.array_equal(got, want, equal_nan=True), (sg.rows, sg.cols, dg.rows, dg.cols)
+        blur_in = np.where(np.isnan(want), np.float32(0), want).astype(np.float32)
+        b_got = solver.blur_costmap(blur_in, dg, pose[2], 0.16, 0.16, 0.017)
+        b_got = b_got[0] if isinstance(b_got, tuple) else b_got
+        b_want, _, _ = oracle.blur(blur_in, odg, np.sin(pose[2]), np.cos(pose[2]), 0.16, 0.16, 0.017)
+        d = _ulp32_diff(np.asarray(b_got, dtype=np.float32).reshape(-1, order="F"), b_want.reshape(-1, order="F"))
+        assert d.max() <= 1, (dg.rows, dg.cols, int(d.max()))
+        occ = solver.layer_to_occupancy(b_want.reshape(-1, order="F"), 0.0, 100.0)
+        assert np.array_equal(occ, oracle.layer_to_occupancy(b_want.reshape(-1, order="F"), 0.0, 100.0))
+        assert np.array_equal(solver.occupancy_to_layer(occ), oracle.occupancy_to_layer(occ), equal_nan=True)
