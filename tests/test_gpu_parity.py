@@ -1089,3 +1089,35 @@ def test_costmap_kernels_on_tiny_and_odd_maps(cilqr, oracle, solver):
         occ = solver.layer_to_occupancy(b_want.reshape(-1, order="F"), 0.0, 100.0)
         assert np.array_equal(occ, oracle.layer_to_occupancy(b_want.reshape(-1, order="F"), 0.0, 100.0))
         assert np.array_equal(solver.occupancy_to_layer(occ), oracle.occupancy_to_layer(occ), equal_nan=True)
+
+
+def test_sampled_obstacles_odd_counts_long_horizon(cilqr, oracle):
+    """Sampled obstacles with 33 samples (not a power of two), a single obstacle and 7 obstacles, horizon 80, one of the
+    obstacles far away for the whole horizon (the whole-obstacle skip) — against the oracle on the materialised scene."""
+    from cilqr_amd import scenes
+    N, B = 80, 24
+    p = cilqr.default_params(N)
+    po = oracle.default_params(N)
+    rng = np.random.default_rng(61)
+    for n_obs, S in ((1, 33), (7, 3)):
+        base = scenes.make_static(B, N, n_obs, p, 800 + n_obs)
+        nom_pose = base["obs_pose"].reshape(B, n_obs, N, 4).copy()
+        nom_pose[:, -1, :, 0] += 500.0  # the last obstacle: half a kilometre away
+        # let the obstacles move: x advances with the step index
+        nom_pose[:, :, :, 0] += 0.2 * np.arange(N)[None, None, :]
+        off = rng.normal(0.0, 1.0, (B, n_obs, S, 3)) * np.array([0.2, 0.2, 0.03])
+        pose = np.repeat(nom_pose[:, :, None, :, :], S, axis=2)
+        pose[..., 0] += off[..., 0][..., None]
+        pose[..., 1] += off[..., 1][..., None]
+        pose[..., 3] += off[..., 2][..., None]
+        dim = np.repeat(base["obs_dim"].reshape(B, n_obs, 1, N, 2), S, axis=2)
+        s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=n_obs * S, device=0)
+        try:
+            got = s.solve_batch_sampled(N, base["x0"], base["U"], base["poly"], base["xplan_fl"], nom_pose.reshape(B, n_obs, 4 * N),
+                                        base["obs_dim"], off, 1.0 / S)
+        finally:
+            s.close()
+        want = oracle.solve_batch(po, N, n_obs * S, base["x0"], base["U"], base["poly"], base["xplan_fl"],
+                                  pose.reshape(B, n_obs * S, 4 * N), dim.reshape(B, n_obs * S, 2 * N), np.full((B, n_obs * S), 1.0 / S),
+                                  threads=min(16, oracle.max_threads()))
+        _compare(got, want, TIGHT, "sampled n_obs=%d S=%d" % (n_obs, S))
