@@ -7,7 +7,8 @@
 
 A step = one pass of the hot path over one batch: `cilqr_solve_batch_device` on BASELINE config 2 (B=1024 seeded synthetic
 scenes, N=50, M=4 obstacles, fp64) with every input already resident in HBM, followed by the min-cost selection
-(`cilqr_argmin_device`; with N > 1 ranks, one RCCL all-gather of 24 bytes per rank — the (J, index) pair and the rank's index offset — SURVEY §8e).  Each rank
+(`cilqr_argmin_global_device`: with N > 1 ranks one RCCL all-gather of 24 bytes per rank — the (J, index) pair and the rank's
+index offset — issued by the library on the handle's own communicator).  Each rank
 owns its own shard of B scenes (weak scaling, no data-path collective).  The warm-start U is restored from a device copy
 inside the timed region, because the solve overwrites it.
 Prints ONE JSON line on rank 0.
@@ -37,6 +38,25 @@ PMC_TRAFFIC_BYTES = {("c2", 1024): 2 * 5657.96e3 + 2560e3,      # profiles/r01_f
                      ("warp", 1024): 2 * 598.438e3 + 4096e3,
                      ("occ", 8192): 2 * 131103e3 + 65536e3}
 FP64_VALU_PEAK_TF = 78.6   # vector fp64 = half the 157.3 TF fp32 vector peak of MI355X_MICROARCH.md
+
+
+def cpu_rate(call, units, min_seconds=2.0, reps=3):
+    """Stable CPU-baseline timing: one untimed call (starts the OpenMP pool, faults the pages in), one calibration call, then
+    `reps` repetitions each looping `call` for at least `min_seconds`; returns (median units/s, relative spread, calls per rep)."""
+    call()
+    t = time.perf_counter()
+    call()
+    one = max(time.perf_counter() - t, 1e-6)
+    n = max(1, int(np.ceil(min_seconds / one)))
+    rates = []
+    for _ in range(reps):
+        t = time.perf_counter()
+        for _ in range(n):
+            call()
+        rates.append(n * units / (time.perf_counter() - t))
+    rates.sort()
+    med = rates[len(rates) // 2]
+    return med, (rates[-1] - rates[0]) / med, n
 
 
 def algorithmic_bytes_per_solve(N, M):
@@ -114,16 +134,20 @@ def bench_warp(args, rank, local_rank, world, dist, dev):
             O.build(ref=False)
             threads = O.max_threads()
             osg, odg = O.map_geom(*c4["src_geom"]), O.map_geom(*c4["dst_geom"])
-            t1 = time.perf_counter()
             nf = 20
-            for k in range(nf):
-                want, _ = O.warp(c4["src"], osg, odg, *poses[k], threads=threads)
-            cpu_s = time.perf_counter() - t1
+            res = {}
+
+            def cpu_call():
+                for k in range(nf):
+                    res["w"], _ = O.warp(c4["src"], osg, odg, *poses[k], threads=threads)
+            rate, spread, calls = cpu_rate(cpu_call, nf)
+            want = res["w"]
             solver.warp_costmap_device(stream, src.data_ptr(), sg, dst.data_ptr(), dg, *poses[nf - 1], 0, oob.data_ptr())
             torch.cuda.synchronize()
             got = dst.cpu().numpy().reshape(dg.cols, dg.rows).T
-            out["cpu_baseline"] = {"value": nf / cpu_s, "unit": "frames/s", "cores": threads, "kind": "port",
-                                   "sample": "the first %d frames of the pose stream, OpenMP over cells" % nf}
+            out["cpu_baseline"] = {"value": rate, "unit": "frames/s", "cores": threads, "kind": "port", "spread": spread,
+                                   "sample": "the first %d frames of the pose stream, OpenMP over cells; one untimed pass, then the "
+                                             "median of 3 repetitions of %d passes (>= 2 s each)" % (nf, calls)}
             out["bit_exact_vs_oracle"] = bool(np.array_equal(got, want, equal_nan=True))
         print(json.dumps(out), flush=True)
     solver.close()
@@ -417,13 +441,89 @@ def bench_plan(args, rank, local_rank, world, dist, dev):
         dist.destroy_process_group()
 
 
+def bench_c1(args, rank, local_rank, world, dist, dev):
+    """BASELINE config 1 — the drop-in case: ONE solve per call (B=1, N=30, M=2; the known-answer scene of SURVEY §8c) through
+    the host-buffer entry point `cilqr_solve_batch`, i.e. what replaces the reference's timed `run_step`
+    (I/ilqr_uncertainty_node.cpp:117-122): H2D of the inputs + the solve + D2H of U, X, J every call.  A step = one call;
+    the latency is the median over --steps calls (default here: 1000)."""
+    import cilqr_amd
+    from cilqr_amd import scenes
+    N, M = 30, 2
+    if args.batch:  # other single-solve shapes: --batch encodes the horizon (50 → M=4, 80 → M=16: the other survey scenes)
+        N = args.batch
+        M = {30: 2, 50: 4, 80: 16}.get(N, 4)
+    steps = args.steps if args.steps != 50 else 1000
+    p = cilqr_amd.default_params(N)
+    sc = scenes.known_answer_scene(N, M, p)
+    solver = cilqr_amd.Solver(p, max_batch=1, max_horizon=N, max_obstacles=M, device=local_rank)
+    lat = []
+    for k in range(args.warmup + steps):
+        t = time.perf_counter()
+        got = solver.solve_batch(N, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"])
+        if k >= args.warmup:
+            lat.append(time.perf_counter() - t)
+    lat = np.array(lat)
+    # device-side part of the same call: the kernel pair between two events on a torch stream, inputs resident
+    dvt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    x0, U0, poly, xpl, pose, dim = (dvt(sc[k]) for k in ("x0", "U", "poly", "xplan_fl", "obs_pose", "obs_dim"))
+    U = U0.clone()
+    X = torch.zeros(4 * (N + 1), dtype=torch.float64, device=dev)
+    J = torch.zeros(1, dtype=torch.float64, device=dev)
+    it = torch.zeros(1, dtype=torch.int32, device=dev)
+    st = torch.zeros(1, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(k, e0, e1):
+        U.copy_(U0)
+        if e0 is not None:
+            e0.record()
+        solver.solve_batch_device(stream, 1, N, M, x0.data_ptr(), U.data_ptr(), poly.data_ptr(), xpl.data_ptr(), pose.data_ptr(),
+                                  dim.data_ptr(), 0, X.data_ptr(), J.data_ptr(), it.data_ptr(), st.data_ptr())
+        if e1 is not None:
+            e1.record()
+    a2 = argparse.Namespace(steps=min(steps, 200), warmup=args.warmup)
+    elapsed, kern_ms = _timed(step, a2, dist, dev)
+    if rank == 0:
+        med = float(np.median(lat))
+        bytes_launch = algorithmic_bytes_per_solve(N, M)
+        out = {"metric": "single CILQR solve latency through cilqr_solve_batch (B=1, N=%d, M=%d)" % (N, M), "value": 1e3 * med,
+               "unit": "ms", "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * med,
+               "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "BASELINE config 1 shape on the GPU: one solve per call, host buffers in and out (pageable), "
+                                      "known-answer scene of SURVEY 8(c)", "horizon": N, "obstacles": M,
+                          "iterations": int(got["iters"][0]), "exit": int(got["status"][0])},
+               "latency_ms": {"median": 1e3 * med, "p10": 1e3 * float(np.percentile(lat, 10)), "p90": 1e3 * float(np.percentile(lat, 90)),
+                              "min": 1e3 * float(lat.min())},
+               "roofline": {"bound": "hbm", "kernel": "cilqr_solve_kernel", "achieved": bytes_launch / (kern_ms * 1e-3) / 1e9,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_launch / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "traffic": None, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch,
+                            "note": "one wavefront on one SIMD: pure serial-chain latency, the rest of the chip idle"}}
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import oracle as O
+            O.build(ref=False)
+            po = O.default_params(N)
+            res = {}
+
+            def cpu_call():
+                res["w"] = O.solve_batch(po, N, M, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"], None, threads=1)
+            rate, spread, calls = cpu_rate(cpu_call, 1)
+            out["cpu_baseline"] = {"value": 1e3 / rate, "unit": "ms", "cores": 1, "kind": "port",
+                                   "sample": "the same scene, one thread; median of 3 repetitions of %d solves" % calls, "spread": spread}
+            out["max_abs_du_vs_oracle"] = float(np.max(np.abs(got["U"] - res["w"]["U"])))
+            out["iters_equal_oracle"] = bool(int(got["iters"][0]) == int(res["w"]["iters"][0]))
+        print(json.dumps(out), flush=True)
+    solver.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=0, help="solves per GPU per step (default: the config's own size)")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "warp", "blur", "occ", "frame", "plan"],
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c5", "warp", "blur", "occ", "frame", "plan"],
                     help="c2 (default, the config BASELINE.json's metric is quoted on): B=1024 N=50 M=4; c3: B=4096 N=50, 8x32 "
                          "sampled obstacles; c5: B=8192 per GPU N=80 M=16; warp: config 4, 1024x1024 costmap frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -449,15 +549,15 @@ def main():
 
     import cilqr_amd
     from cilqr_amd import scenes
-    from cilqr_amd.dist import select_min_cost
+    from cilqr_amd.dist import init_comm, select_min_cost_device
 
     dev = torch.device("cuda", local_rank)
     if args.workload == "warp":
         return bench_warp(args, rank, local_rank, world, dist, dev)
     if args.workload == "blur":
         return bench_blur(args, rank, local_rank, world, dist, dev)
-    if args.workload in ("occ", "frame", "plan"):
-        return {"occ": bench_occ, "frame": bench_frame, "plan": bench_plan}[args.workload](args, rank, local_rank, world, dist, dev)
+    if args.workload in ("occ", "frame", "plan", "c1"):
+        return {"occ": bench_occ, "frame": bench_frame, "plan": bench_plan, "c1": bench_c1}[args.workload](args, rank, local_rank, world, dist, dev)
     if args.workload == "c2":
         B, N, M = args.batch or 1024, 50, 4
         p = cilqr_amd.default_params(N)
@@ -476,6 +576,8 @@ def main():
         wl = ("BASELINE config 3: B=%d CILQR solves per GPU per step, N=50, 8 moving obstacles x 32 Gaussian samples (M=256, weight 1/32), "
               % B) + ("materialised obstacle tables" if args.materialised else "compact form (nominal trajectories + sample offsets)")
     solver = cilqr_amd.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M, device=local_rank)
+    if dist is not None:  # one RCCL communicator over the ranks, owned by the handle: the exchange step is a C-ABI call
+        init_comm(solver, dist)
 
     def dv(a, dtype=torch.float64):
         return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).to(dev)
@@ -494,6 +596,8 @@ def main():
     iters = torch.zeros(B, dtype=torch.int32, device=dev)
     status = torch.zeros(B, dtype=torch.int32, device=dev)
     pair = torch.zeros(2, dtype=torch.float64, device=dev)
+    passes = torch.zeros(B, dtype=torch.int32, device=dev)
+    solver.set_pass_count_buffer(passes.data_ptr())  # executed backward+forward passes per solve (one int32 store per solve)
     stream = torch.cuda.current_stream().cuda_stream
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -512,8 +616,8 @@ def main():
                                       iters.data_ptr(), status.data_ptr())
         if k is not None:
             ev1[k].record()
-        solver.argmin_device(stream, B, J.data_ptr(), pair.data_ptr())
-        return select_min_cost(pair, rank * B, dist)  # all-gather of 16-byte pairs when world > 1
+        # local argmin + ONE ncclAllGather of 24 bytes per rank + the pick, all enqueued by cilqr_argmin_global_device
+        return select_min_cost_device(solver, stream, B, J.data_ptr(), rank * B, pair)
 
     for _ in range(args.warmup):
         step()
@@ -539,6 +643,10 @@ def main():
     total_solves = B * world * args.steps
     value = total_solves / elapsed
     mean_iters = float(iters.float().mean().item())
+    mean_passes = float(passes.float().mean().item())
+    # linearisations executed: every pass is preceded by one, and a solve that stops on a rejection did one more
+    st_h = status.cpu().numpy()
+    mean_lin = mean_passes + float(np.mean(st_h != 0))
 
     out = None
     if rank == 0:
@@ -546,15 +654,18 @@ def main():
         if sampled:  # SURVEY §8(d) compact form: nominal 6·n_dyn·N + 3 offsets per sample instead of 6·M·N
             bytes_launch = (8 * (4 + 2 * N + 6 + 2 + 6 * n_dyn * N + 3 * n_dyn * n_smp) + 8 * (2 * N + 4 * (N + 1) + 1) + 8) * B
         achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
-        # fp64 VALU work actually needed per solve: accepted iterations k = (iters - 5)/2 for λ-exits
-        flops_solve = mean_iters * N * (6 * 200 + 100 * M + 800)
+        # F = I·N·(6·S + 100·M + 800) fp64 flops per solve, S = 200.  Priced twice: with I = the reference loop's
+        # iteration count (what the CPU reference executes) and with the passes the kernel actually executes (it stops at the
+        # first rejected iteration): linearisations·N·(6S + 100M) + passes·N·800.
+        flops_ref = mean_iters * N * (6 * 200 + 100 * M + 800)
+        flops_solve = mean_lin * N * (6 * 200 + 100 * M) + mean_passes * N * 800
         out = {
             "metric": "CILQR solves/sec (N=%d, batch B)" % N, "value": value, "unit": "solves/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl + ", inputs resident in HBM, + min-cost selection",
                        "batch_per_gpu": B, "horizon": N, "obstacles": M, "mean_reference_iterations": mean_iters,
-                       "parallelism": "scene-sharded x%d, RCCL all-gather of (J,index)" % world},
+                       "parallelism": "scene-sharded x%d, one ncclAllGather of 24 B per rank behind cilqr_argmin_global_device" % world},
             "roofline": {"bound": "hbm", "kernel": "cilqr_solve_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if (args.workload == "c3" and args.materialised) else PMC_TRAFFIC_BYTES.get((args.workload, B)),
@@ -563,7 +674,12 @@ def main():
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch,
                          "note": "latency/fp64-VALU-bound path: HBM fraction is tiny by design (LDS-resident solve); see fp64_valu"},
             "fp64_valu": {"achieved_tflops_est": flops_solve * B / (kern_ms * 1e-3) / 1e12, "peak_tflops": FP64_VALU_PEAK_TF,
-                          "flops_per_solve_est": flops_solve},
+                          "frac": flops_solve * B / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
+                          "flops_per_solve_executed": flops_solve, "mean_executed_passes": mean_passes,
+                          "mean_executed_linearisations": mean_lin,
+                          "reference_iteration_figure": {"flops_per_solve": flops_ref,
+                                                         "tflops": flops_ref * B / (kern_ms * 1e-3) / 1e12,
+                                                         "note": "counts the rejected iterations the reference loop repeats and the kernel skips"}},
             "min_cost": {"J": best[0], "global_index": best[1]},
         }
         # SURVEY §8(d) also asks for the host-buffer entry point (H2D + kernel + D2H); reported, never `value`
@@ -586,16 +702,20 @@ def main():
             O.build(ref=False)
             threads = O.max_threads()
             po = O.default_params(N)
-            t1 = time.perf_counter()
-            ns = min(B, 1024 if M <= 16 else 128)  # bounded sample: ≈10-30 s of CPU work
-            sl = lambda a: None if a is None else a[:ns]  # noqa: E731
-            want = O.solve_batch(po, N, M, sl(sc["x0"]), sl(sc["U"]), sl(sc["poly"]), sl(sc["xplan_fl"]), sl(sc["obs_pose"]),
-                                 sl(sc["obs_dim"]), sl(sc["obs_weight"]), threads=threads)
-            cpu_s = time.perf_counter() - t1
+            ns = min(B, 1024 if M <= 16 else 128)  # bounded sample
+            sl = lambda a: None if a is None else np.ascontiguousarray(a[:ns])  # noqa: E731
+            sample = [sl(sc[k]) for k in ("x0", "U", "poly", "xplan_fl", "obs_pose", "obs_dim", "obs_weight")]
+            res = {}
+
+            def cpu_call():
+                res["want"] = O.solve_batch(po, N, M, *sample, threads=threads)
+            rate, spread, calls = cpu_rate(cpu_call, ns)
+            want = res["want"]
             du = float(np.max(np.abs(U.cpu().numpy()[:ns] - want["U"])))
-            out["cpu_baseline"] = {"value": ns / cpu_s, "unit": "solves/s", "cores": threads, "kind": "port",
-                                   "sample": "the first %d scenes of the same batch, once, OpenMP over the batch" % ns,
-                                   "per_core": ns / cpu_s / threads}
+            out["cpu_baseline"] = {"value": rate, "unit": "solves/s", "cores": threads, "kind": "port",
+                                   "sample": "the first %d scenes of the same batch, OpenMP schedule(dynamic) over the batch; one untimed "
+                                             "call, then the median of 3 repetitions of %d calls (>= 2 s each)" % (ns, calls),
+                                   "spread": spread, "per_core": rate / threads}
             out["max_abs_du_vs_oracle"] = du
             out["iters_equal_oracle"] = bool(np.array_equal(iters.cpu().numpy()[:ns], want["iters"]))
         print(json.dumps(out), flush=True)

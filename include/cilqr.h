@@ -22,7 +22,8 @@
  *                                                                cilqr_local_plan_batch(_device) (B candidates on the device)
  *   LocalCostmap::odomCallback warp loop M/src/local_costmap.cpp:242-264 cilqr_warp_costmap(_device)
  *   thrust_propagateUncertainty     M/src/arbitrary_transformation.cu:8-157  cilqr_blur_costmap(_device)
- *   (none: batch min-cost selection is new)      cilqr_argmin_device
+ *   (none: batch min-cost selection is new)      cilqr_argmin_device, cilqr_argmin_global_device (RCCL),
+ *                                                                cilqr_create_multi / cilqr_multi_solve_batch
  *
  * Conventions
  *   - fp64 everywhere in the solver; float32 map payloads in the warp.
@@ -54,7 +55,8 @@ extern "C" {
 #define CILQR_NU 2
 #define CILQR_POLY_COEFFS 6   /* poly_order + 1, I/Parameters.cpp:7 */
 #define CILQR_MAX_HORIZON 384  /* per-solve arrays of the LDS-resident family at the default sample count: 132 KiB of 160 */
-#define CILQR_ABI_VERSION 1
+#define CILQR_ABI_VERSION 2
+#define CILQR_COMM_ID_BYTES 128 /* an RCCL ncclUniqueId, carried opaquely */
 
 /* Field-for-field POD mirror of class Parameters (I/Parameters.h:5-91) — only the fields the
  * constructor initialises (I/Parameters.cpp:6-74) — plus the two constants iLQR::iLQR sets
@@ -102,7 +104,8 @@ typedef enum cilqr_status {
   CILQR_ERR_ARG = -1,        /* bad argument (null pointer, size out of the range given at create) */
   CILQR_ERR_NO_DEVICE = -2,  /* no usable gfx950 device / HIP runtime error at create */
   CILQR_ERR_HIP = -3,        /* HIP runtime error during a call */
-  CILQR_ERR_UNSUPPORTED = -4 /* parameter combination the kernels do not implement (e.g. num_states != 4) */
+  CILQR_ERR_UNSUPPORTED = -4,/* parameter combination the kernels do not implement (e.g. num_states != 4) */
+  CILQR_ERR_COMM = -5        /* RCCL error in the cross-GPU exchange step */
 } cilqr_status;
 
 /* Per-solve exit reason written to status_out (I/iLQR.cpp:211-239). */
@@ -134,6 +137,7 @@ typedef struct cilqr_map_geom {
 /* --- parameters ------------------------------------------------------------------------------- */
 void cilqr_params_default(cilqr_params* p);             /* I/Parameters.cpp:3-75 + I/iLQR.cpp:17-18 */
 int  cilqr_abi_version(void);
+int  cilqr_device_count(void);  /* gfx950 devices this process can use (0: none; there is no CPU path) */
 const char* cilqr_last_error(void);
 
 /* Initial warm-start control sequence of a fresh planner (I/iLQR.cpp:9-15): row 0 = 0.5, row 1 = 0 for
@@ -221,14 +225,59 @@ int cilqr_solve_batch_sampled_device(cilqr_handle* h, void* stream, int B, int N
 
 /* Local min-cost selection over a batch resident on the device (strict-< first-minimum tie-break, as in
  * I/Constraints.cpp:50): writes {J_min, (double)index} to out_pair (device, 2 doubles).  The cross-GPU step
- * is one all-gather of these 16-byte pairs (RCCL), done by the caller's communicator. */
+ * is cilqr_argmin_global_device below. */
 int cilqr_argmin_device(cilqr_handle* h, void* stream, int B, const double* J, double* out_pair);
+
+/* --- the cross-GPU exchange step (SURVEY §8b "Entry point", §8e; new: the reference has no collective) ------------------
+ * The batch shards by scene with no data-path collective; the ONE exchange is the min-cost pick: every rank's
+ * {J_min, local index, index offset} (24 bytes) through one ncclAllGather (RCCL over xGMI), then the lexicographic minimum
+ * on the device, lowest global index winning ties (the strict-< first-minimum convention of I/Constraints.cpp:50).
+ *
+ * One process per GPU: rank 0 calls cilqr_comm_unique_id (ncclGetUniqueId), the host carries the CILQR_COMM_ID_BYTES to every
+ * rank by its own means (MPI_Bcast, a file, torch.distributed's store), every rank calls cilqr_comm_init_rank on its handle
+ * (ncclCommInitRank: collective, blocks until all ranks arrive).  cilqr_destroy releases the communicator. */
+int cilqr_comm_unique_id(void* id_bytes /* CILQR_COMM_ID_BYTES, out */);
+int cilqr_comm_init_rank(cilqr_handle* h, int n_ranks, int rank, const void* id_bytes);
+int cilqr_comm_destroy(cilqr_handle* h);
+int cilqr_comm_size(const cilqr_handle* h); /* ranks of the handle's communicator; 1 without one */
+/* Global min-cost selection, asynchronous on `stream`: argmin of this rank's J[B] (device; B = 0: the rank has no scenes) →
+ * all-gather → out_pair (device, 2 doubles) = {J_min, (double)global index}, the same on every rank; global index =
+ * index_offset + local index; index -1: no rank had a finite cost.  Without a communicator it is the local pick plus offset.
+ * Every rank of the communicator must call it, in the same order relative to its other collective calls. */
+int cilqr_argmin_global_device(cilqr_handle* h, void* stream, int B, const double* J, int64_t index_offset, double* out_pair);
+
+/* Test hook: the cross-rank pick alone, over n gathered records {J_min, local index, index offset} given in host memory →
+ * out_pair (host, 2 doubles).  Lets the device-side combine rule be checked for several ranks on a one-GPU box. */
+int cilqr_debug_select(cilqr_handle* h, int n, const double* triples, double* out_pair);
+
+/* One process driving n_devices GPUs (the host model of the reference: one C++ process): one handle, stream and RCCL
+ * communicator per device (ncclCommInitAll); devices = NULL means ordinals 0..n_devices-1.  Mirrors
+ * iLQR::iLQR / get_optimal_control_seq like cilqr_create / cilqr_solve_batch do, for a batch that spans devices. */
+typedef struct cilqr_multi cilqr_multi;
+int cilqr_create_multi(const cilqr_params* p, int max_batch_per_device, int max_horizon, int max_obstacles, int n_devices,
+                       const int* devices, cilqr_multi** out);
+int cilqr_multi_destroy(cilqr_multi* m);
+int cilqr_multi_device_count(const cilqr_multi* m);
+cilqr_handle* cilqr_multi_handle(cilqr_multi* m, int i); /* device i's handle, for the *_device entry points */
+/* cilqr_solve_batch over all devices: host buffers as there, solves sharded contiguously (device d owns
+ * [d·ceil(B/n), (d+1)·ceil(B/n)) ∩ [0, B)), every device's copies and kernels enqueued before any wait, followed by the exchange
+ * step; best_index / best_J (may be NULL) receive the global min-cost pick. */
+int cilqr_multi_solve_batch(cilqr_multi* m, int B, int N, int M, const double* x0, double* U, const double* poly,
+                            const double* xplan_fl, const double* obs_pose, const double* obs_dim, const double* obs_weight,
+                            double* X_out, double* J_out, int32_t* iters_out, int32_t* status_out, uint32_t flags,
+                            int64_t* best_index, double* best_J);
 
 /* Diagnostics (the reference's only tracing is std::chrono around run_step, I/ilqr_uncertainty_node.cpp:117-124): while
  * dev_buf != NULL, solves run a separately compiled, stamped instantiation of the kernel that writes, per solve, 8
  * uint64 shader-clock totals {prologue, linearise, Riccati, forward, epilogue, #linearise, #Riccati, total} to
  * dev_buf[B][8] (device memory owned by the caller).  NULL restores the production kernel.  Never use it when timing. */
 int cilqr_set_diag_buffer(cilqr_handle* h, uint64_t* dev_buf);
+
+/* Measurement hook: while dev_buf != NULL every solve also writes the number of backward + forward passes it actually
+ * executed to dev_buf[B] (device int32, owned by the caller).  The production kernels stop at the first rejected iteration
+ * (DESIGN.md §4.3), so this is smaller than iters_out, the reference loop's iteration count; bench.py prices its fp64 estimate
+ * with it.  NULL switches it off. */
+int cilqr_set_pass_count_buffer(cilqr_handle* h, int32_t* dev_buf);
 
 /* Test hook: runs the kernels' own regularised Q_uu inverse (I/iLQR.cpp:155-175) on n column-major 2×2 matrices (host
  * buffers).  general = 0: the positive-semi-definite form of the production kernel; 1: the eigenvalue-clamping form of the

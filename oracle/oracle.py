@@ -133,7 +133,30 @@ def solve_batch(p, N, M, x0, U, poly, xplan_fl, obs_pose=None, obs_dim=None, obs
 
 
 def max_threads():
-    return int(lib().oracle_max_threads())
+    """Threads the OpenMP loops should use: the CPUs this process may really run on — its affinity mask, cut down to the
+    cgroup CPU quota when there is one (a GPU box hands a 1-GPU job a share of the host's cores; more threads than that are
+    throttled in bursts and make timings noisy)."""
+    n = int(lib().oracle_max_threads())
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, int(q / float(f.read()) + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
 
 
 def local_plan(p, path, ego):

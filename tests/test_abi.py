@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(cilqr):
     assert declared == set(cilqr.ABI_SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.cilqr_abi_version() == 1
+    assert L.cilqr_abi_version() == 2
 
 
 def test_struct_layouts_agree(cilqr, oracle):

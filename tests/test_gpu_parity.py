@@ -372,7 +372,9 @@ def _ulp32_diff(a, b):
     ((30.0, 20.0, 0.2, 15.0, 0.0), (0.16, 0.16, 0.017), -1.2, 0),      # the node's default vehicle map, launch-file sigmas
     ((30.0, 20.0, 0.2, 15.0, 0.0), (0.005, 0.005, 0.0125), 0.3, 40),   # dynamic_reconfigure defaults: many NaN-axis cells
     ((30.0, 20.0, 0.2, 10.0, 0.0), (0.3, 0.2, 0.05), 2.5, 0),          # large ellipses (up to ~370 cells)
-    ((102.4, 102.4, 0.1, 5.0, -3.0), (0.16, 0.16, 0.017), 0.3, 0),     # 1024 × 1024 cells
+    ((102.4, 102.4, 0.1, 5.0, -3.0), (0.16, 0.16, 0.017), 0.3, 0),     # 1024 × 1024 cells (one lane per cell)
+    ((40.0, 30.0, 0.1, 12.0, 1.5), (0.16, 0.16, 0.017), 0.9, 7),       # 400 × 300 cells: the 4-lanes-per-cell instantiation
+    ((25.6, 25.6, 0.1, 0.0, 0.0), (0.1, 0.25, 0.03), -2.2, 0),         # 256 × 256 cells: 4 lanes per cell, anisotropic sigmas
 ])
 def test_blur_kernel_vs_oracle(cilqr, oracle, solver, geom, sigma, theta, index):
     """Fused blur kernel against the oracle (itself bit-equal to the reference's grid_map_core + Eigen, tests/test_oracle.py).
@@ -845,6 +847,12 @@ def test_closest_point_windows_on_steep_and_distant_paths(cilqr, oracle, G, monk
     ok = np.isfinite(want["U"]).all(axis=1)
     assert ok.sum() >= B * 0.9
     _compare({k: v[ok] for k, v in got.items()}, {k: v[ok] for k, v in want.items()}, 1e-8, "closest-point windows G=%d" % G)
+    # scenes the oracle leaves non-finite (a far ego on a steep path overflows the barrier exponentials): the kernels must
+    # report them the same way — same exit reason, same iteration count, no finite-looking trajectory
+    bad = ~ok
+    assert np.array_equal(got["status"][bad], want["status"][bad])
+    assert np.array_equal(got["iters"][bad], want["iters"][bad])
+    assert (~np.isfinite(got["U"][bad]).all(axis=1) | (got["status"][bad] == cilqr.EXIT_NUMERIC)).all()
 
 
 @pytest.mark.parametrize("G", [1, 8, 32])
@@ -1121,3 +1129,176 @@ def test_sampled_obstacles_odd_counts_long_horizon(cilqr, oracle):
                                   pose.reshape(B, n_obs * S, 4 * N), dim.reshape(B, n_obs * S, 2 * N), np.full((B, n_obs * S), 1.0 / S),
                                   threads=min(16, oracle.max_threads()))
         _compare(got, want, TIGHT, "sampled n_obs=%d S=%d" % (n_obs, S))
+
+
+def test_config3_full_batch_properties(cilqr, oracle):
+    """BASELINE config 3 at its full size (B = 4096, N = 50, 8 moving obstacles x 32 samples, compact entry point) through
+    size-independent properties: a 128-solve sample against the oracle on the materialised 256-obstacle scene; permutation
+    equivariance (every solve then runs in another workgroup); idempotence."""
+    from cilqr_amd import scenes
+    N, B = 50, 4096
+    p = cilqr.default_params(N)
+    sc = scenes.make_c3(B, p)
+    s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=sc["M"], device=0)
+
+    def run(c):
+        return s.solve_batch_sampled(N, c["x0"], c["U"], c["poly"], c["xplan_fl"], c["nom_pose"], c["nom_dim"], c["offsets"],
+                                     c["sample_weight"])
+    try:
+        got = run(sc)
+        again = run(sc)
+        perm = np.random.default_rng(5).permutation(B)
+        scp = dict(sc)
+        for k in ("x0", "U", "poly", "xplan_fl", "nom_pose", "nom_dim", "offsets"):
+            scp[k] = np.ascontiguousarray(sc[k][perm])
+        gotp = run(scp)
+    finally:
+        s.close()
+    for k in ("U", "X", "J", "iters", "status"):
+        assert np.array_equal(got[k], again[k]), k
+        assert np.array_equal(got[k][perm], gotp[k]), k
+    idx = np.concatenate([np.arange(48), np.arange(2000, 2040), np.arange(B - 40, B)])
+    sub = {k: (v[idx] if isinstance(v, np.ndarray) else v) for k, v in sc.items()}
+    _compare({k: v[idx] for k, v in got.items()}, _oracle_batch(oracle, N, sub), 1e-9, "c3 full batch sample")
+    assert np.isfinite(got["U"]).all()
+
+
+def test_pass_count_buffer(cilqr, oracle):
+    """cilqr_set_pass_count_buffer: executed backward+forward passes per solve.  With the early exit a solve that stops on
+    a rejection after r accepted iterations executed r passes; one that stops on the tolerance executed `iters` passes; under
+    CILQR_FLAG_FAITHFUL_ITERS every reference iteration is a pass.  Both kernel families."""
+    import torch
+    from cilqr_amd import scenes
+    N, M = 50, 4
+    p = cilqr.default_params(N)
+    for B in (96, 2048):  # wavefront family; grouped family
+        sc = scenes.make_static(B, N, M, p, 777)
+        s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M, device=0)
+        try:
+            dev = torch.device("cuda", 0)
+            t = {k: torch.from_numpy(np.ascontiguousarray(sc[k])).to(dev) for k in ("x0", "U", "poly", "xplan_fl", "obs_pose", "obs_dim")}
+            X = torch.zeros(B, 4 * (N + 1), dtype=torch.float64, device=dev)
+            J = torch.zeros(B, dtype=torch.float64, device=dev)
+            it = torch.zeros(B, dtype=torch.int32, device=dev)
+            st = torch.zeros(B, dtype=torch.int32, device=dev)
+            ps = torch.full((B,), -1, dtype=torch.int32, device=dev)
+            s.set_pass_count_buffer(ps.data_ptr())
+            stream = torch.cuda.current_stream().cuda_stream
+            out = {}
+            for flags in (0, cilqr.FLAG_FAITHFUL_ITERS):
+                U = t["U"].clone()
+                s.solve_batch_device(stream, B, N, M, t["x0"].data_ptr(), U.data_ptr(), t["poly"].data_ptr(), t["xplan_fl"].data_ptr(),
+                                     t["obs_pose"].data_ptr(), t["obs_dim"].data_ptr(), 0, X.data_ptr(), J.data_ptr(), it.data_ptr(),
+                                     st.data_ptr(), flags)
+                torch.cuda.synchronize()
+                out[flags] = (ps.cpu().numpy().copy(), it.cpu().numpy().copy(), st.cpu().numpy().copy())
+            s.set_pass_count_buffer(0)
+        finally:
+            s.close()
+        ps0, it0, st0 = out[0]
+        psf, itf, stf = out[cilqr.FLAG_FAITHFUL_ITERS]
+        assert np.array_equal(it0, itf) and np.array_equal(st0, stf)
+        tol = st0 == cilqr.EXIT_TOLERANCE
+        assert np.array_equal(ps0[tol], it0[tol])
+        # a rejection after r accepted iterations: the reference loop then only multiplies lamb (1/10^r by repeated division) by
+        # 10 per iteration until it passes lamb_max or the iteration cap — replayed here in the same double arithmetic
+        def replay(r):
+            lamb = 1.0
+            for _ in range(r):
+                lamb = lamb / p.lamb_factor
+            k = r + 1
+            while True:
+                lamb = lamb * p.lamb_factor
+                if lamb > p.lamb_max:
+                    return k, cilqr.EXIT_LAMBDA_MAX
+                if k >= p.max_iterations:
+                    return k, cilqr.EXIT_MAX_ITER
+                k += 1
+        rej = ~tol & (st0 != cilqr.EXIT_NUMERIC)
+        want = np.array([replay(int(r)) for r in ps0[rej]]).reshape(-1, 2)
+        full = ps0[rej] == p.max_iterations  # all max_iterations iterations accepted: no rejection at all
+        assert np.array_equal(want[~full, 0], it0[rej][~full]) and np.array_equal(want[~full, 1], st0[rej][~full])
+        assert (ps0 >= 0).all() and (ps0 <= it0).all()
+        # faithful loop: every iteration runs both passes, except the last when it ends on lamb > lamb_max after its passes
+        assert (psf >= ps0).all() and (psf <= itf).all() and (psf[~tol] >= itf[~tol] - 1).all()
+
+
+def test_run_step_and_run_candidates_agree(cilqr, oracle, tmp_path):
+    """iLQR::run_step uses the host pre-step (libm pow in the Vandermonde matrix), run_candidates the device fit (correctly
+    rounded powers): the two local plans differ in the last bits about once per thousand fits.  One candidate through either
+    route must give the same trajectory to well within the solver tolerance."""
+    import os
+    import subprocess
+    from conftest import PKG, ROOT
+    exe = str(tmp_path / "step_vs_candidates")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "host"), "-o", exe,
+                    os.path.join(ROOT, "tests", "cpp", "step_vs_candidates.cpp"), "-L" + os.path.join(PKG, "lib"), "-lcilqr_hip",
+                    "-Wl,-rpath," + os.path.join(PKG, "lib")], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    worst = float(r.stdout.strip().split()[-1])
+    assert worst <= 1e-9, r.stdout
+
+
+# ---- the cross-GPU exchange step behind the C-ABI (csrc/cilqr_comm.cpp) ------------------------------------------------------
+def test_cross_rank_select_rule_on_device(cilqr, solver):
+    """select_kernel — the pick over the gathered per-rank records — on the cases the world-size-2 gloo test runs through
+    the torch path (tests/test_multi_rank.py): rank without a finite cost, NaN, ties resolved by the lowest GLOBAL index."""
+    from test_multi_rank import CASES, EXPECT
+    for (per_rank, shard), (ej, ei) in zip(CASES, EXPECT):
+        triples = [[p[0], p[1], r * shard] for r, p in enumerate(per_rank)]
+        j, i = solver.debug_select(triples)
+        assert i == ei and (j == ej or (j != j and ej != ej)), (triples, j, i)
+    rng = np.random.default_rng(17)  # 70 ranks (more than one wavefront's worth of records), duplicated minima
+    J = rng.integers(0, 9, 70).astype(float)
+    idx = rng.integers(0, 50, 70).astype(float)
+    off = np.arange(70) * 50.0
+    j, i = solver.debug_select(np.stack([J, idx, off], 1))
+    glob = idx + off
+    k = np.lexsort((glob, J))[0]
+    assert (j, i) == (J[k], int(glob[k]))
+
+
+def test_argmin_global_device_single_rank_and_rccl_world1(cilqr, solver):
+    """cilqr_argmin_global_device: without a communicator it is the local pick plus the offset; with a one-rank RCCL
+    communicator (unique id → ncclCommInitRank → ncclAllGather, all through the C-ABI) the result is the same."""
+    import torch
+    dev = torch.device("cuda", 0)
+    J = torch.tensor([5.0, float("nan"), 2.5, 7.0, 2.5, float("inf")], dtype=torch.float64, device=dev)
+    pair = torch.zeros(2, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    solver.argmin_global_device(stream, 6, J.data_ptr(), 1000, pair.data_ptr())
+    assert pair.tolist() == [2.5, 1002.0]
+    solver.argmin_global_device(stream, 0, 0, 1000, pair.data_ptr())  # a rank without scenes
+    assert pair.tolist() == [float("inf"), -1.0]
+    s = cilqr.Solver(cilqr.default_params(), max_batch=8, max_horizon=8, max_obstacles=0, device=0)
+    try:
+        assert s.comm_size() == 1
+        s.comm_init_rank(1, 0, cilqr.comm_unique_id())
+        assert s.comm_size() == 1
+        s.argmin_global_device(stream, 6, J.data_ptr(), 64, pair.data_ptr())
+        assert pair.tolist() == [2.5, 66.0]
+        with pytest.raises(cilqr.CilqrError):
+            s.comm_init_rank(1, 0, cilqr.comm_unique_id())  # already has a communicator
+    finally:
+        s.close()
+
+
+def test_cpp_host_shards_over_all_devices(cilqr, tmp_path):
+    """tests/cpp/multi_device.cpp: a C++ host with no Python in it runs one batch over hipGetDeviceCount() devices through
+    cilqr_create_multi / cilqr_multi_solve_batch (RCCL exchange inside) — bit-equal to the single-handle batch and pick."""
+    import json
+    import os
+    import subprocess
+    from conftest import PKG, ROOT
+    exe = str(tmp_path / "multi_device")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                    os.path.join(ROOT, "tests", "cpp", "multi_device.cpp"), "-L" + os.path.join(PKG, "lib"), "-lcilqr_hip",
+                    "-Wl,-rpath," + os.path.join(PKG, "lib")], check=True)
+    n = cilqr.lib().cilqr_device_count()
+    assert n >= 1
+    for B in (37, 5):
+        r = subprocess.run([exe, str(B)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out = json.loads(r.stdout)
+        assert out["bit_equal"] and out["devices"] == n and out["best_single"] == out["best_multi"]

@@ -18,11 +18,13 @@ EXIT_TOLERANCE, EXIT_LAMBDA_MAX, EXIT_MAX_ITER, EXIT_NUMERIC = 0, 1, 2, 3
 
 # every symbol include/cilqr.h declares
 ABI_SYMBOLS = (
-    "cilqr_params_default", "cilqr_abi_version", "cilqr_last_error", "cilqr_default_control_seq",
+    "cilqr_params_default", "cilqr_abi_version", "cilqr_device_count", "cilqr_last_error", "cilqr_default_control_seq",
     "cilqr_local_plan", "cilqr_local_plan_batch", "cilqr_local_plan_batch_device", "cilqr_create", "cilqr_destroy", "cilqr_solve_batch", "cilqr_solve_batch_device", "cilqr_solve_batch_sampled", "cilqr_solve_batch_sampled_device",
-    "cilqr_argmin_device", "cilqr_wait", "cilqr_set_diag_buffer", "cilqr_debug_quu_inverse", "cilqr_debug_blur_ellipse", "cilqr_warp_costmap", "cilqr_warp_costmap_device", "cilqr_blur_costmap", "cilqr_blur_costmap_device", "cilqr_map_geom_set",
+    "cilqr_argmin_device", "cilqr_wait", "cilqr_set_diag_buffer", "cilqr_set_pass_count_buffer", "cilqr_debug_quu_inverse", "cilqr_debug_blur_ellipse", "cilqr_warp_costmap", "cilqr_warp_costmap_device", "cilqr_blur_costmap", "cilqr_blur_costmap_device", "cilqr_map_geom_set",
     "cilqr_occupancy_to_layer", "cilqr_occupancy_to_layer_device", "cilqr_layer_to_occupancy", "cilqr_layer_to_occupancy_device",
     "cilqr_costmap_frame_device",
+    "cilqr_comm_unique_id", "cilqr_comm_init_rank", "cilqr_comm_destroy", "cilqr_comm_size", "cilqr_argmin_global_device", "cilqr_debug_select",
+    "cilqr_create_multi", "cilqr_multi_destroy", "cilqr_multi_device_count", "cilqr_multi_handle", "cilqr_multi_solve_batch",
 )
 
 _dp = C.POINTER(C.c_double)
@@ -71,6 +73,16 @@ def lib():
             getattr(L, name)  # AttributeError if a declared symbol is not exported
         _lib = L
     return _lib
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the C-ABI: 128 opaque bytes for `Solver.comm_init_rank` on every rank."""
+    buf = (C.c_char * COMM_ID_BYTES)()
+    _check(lib().cilqr_comm_unique_id(buf))
+    return bytes(buf.raw)
 
 
 def _check(rc):
@@ -233,8 +245,29 @@ class Solver:
     def argmin_device(self, stream, B, J, out_pair):
         _check(lib().cilqr_argmin_device(self._h, _vp(stream), int(B), _vp(J), _vp(out_pair)))
 
+    # ---- cross-GPU exchange step (RCCL behind the C-ABI) ----
+    def comm_init_rank(self, n_ranks, rank, id_bytes):
+        """id_bytes: the 128 bytes of `comm_unique_id()` made on one rank and carried to the others by the host."""
+        buf = (C.c_char * COMM_ID_BYTES).from_buffer_copy(bytes(id_bytes))
+        _check(lib().cilqr_comm_init_rank(self._h, int(n_ranks), int(rank), buf))
+
+    def comm_size(self):
+        return int(lib().cilqr_comm_size(self._h))
+
+    def argmin_global_device(self, stream, B, J, index_offset, out_pair):
+        _check(lib().cilqr_argmin_global_device(self._h, _vp(stream), int(B), _vp(J), C.c_int64(index_offset), _vp(out_pair)))
+
+    def debug_select(self, triples):
+        t = _np64(triples).reshape(-1, 3)
+        out = np.zeros(2)
+        _check(lib().cilqr_debug_select(self._h, int(t.shape[0]), _p(t), _p(out)))
+        return float(out[0]), int(out[1])
+
     def set_diag_buffer(self, dev_ptr):
         _check(lib().cilqr_set_diag_buffer(self._h, _vp(dev_ptr)))
+
+    def set_pass_count_buffer(self, dev_ptr):
+        _check(lib().cilqr_set_pass_count_buffer(self._h, _vp(dev_ptr)))
 
     def debug_quu_inverse(self, Quu, lamb, general=True):
         Quu = _np64(Quu).reshape(-1, 4)

@@ -11,8 +11,9 @@
 
 #include "cilqr_internal.h"
 
-namespace {
+#include "cilqr_handle.h"
 
+namespace cilqr {
 thread_local std::string g_last_error;
 
 int fail(int code, const char* fmt, ...) {
@@ -24,38 +25,9 @@ int fail(int code, const char* fmt, ...) {
   g_last_error = buf;
   return code;
 }
+}  // namespace cilqr
 
-#define HIP_TRY(expr)                                                                              \
-  do {                                                                                             \
-    hipError_t e_ = (expr);                                                                        \
-    if (e_ != hipSuccess) return fail(CILQR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-  } while (0)
-
-}  // namespace
-
-struct cilqr_handle {
-  cilqr_params params;
-  cilqr::KParams kp;
-  int device;
-  int max_batch, max_horizon, max_obstacles;
-  hipStream_t stream;
-  // device staging for the host-pointer entry points
-  double *d_x0, *d_U, *d_poly, *d_xplan, *d_obs_pose, *d_obs_dim, *d_obs_w, *d_samp_off, *d_X, *d_J;
-  int32_t *d_iters, *d_status;
-  // workspace
-  double* d_obs_tab;
-  double* d_ws;      // workspace of the G-lanes-per-solve kernel family
-  int32_t* d_redo;
-  int force_g;       // 0 = automatic; else 1,2,4,8,16,32 or 64 (test hook: environment CILQR_FORCE_G at create)
-  double* d_pair;
-  // warp staging (grown on demand by the host-pointer warp entry point only)
-  float *d_src, *d_dst, *d_bbox;
-  size_t src_cap, dst_cap, bbox_cap;
-  unsigned long long* d_oob;
-  float* d_occ_steps;  // 8 x 128 floats: step tables of the layer -> occupancy conversion (rebuilt per call on the call's stream)
-  unsigned occ_slot;
-  unsigned long long* diag;  // caller-owned device buffer or null
-};
+using cilqr::fail;
 
 namespace {
 
@@ -99,7 +71,18 @@ extern "C" {
 
 int cilqr_abi_version(void) { return CILQR_ABI_VERSION; }
 
-const char* cilqr_last_error(void) { return g_last_error.c_str(); }
+int cilqr_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+  int usable = 0;
+  for (int d = 0; d < count; ++d) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++usable;
+  }
+  return usable;
+}
+
+const char* cilqr_last_error(void) { return cilqr::g_last_error.c_str(); }
 
 void cilqr_params_default(cilqr_params* p) {
   if (!p) return;
@@ -186,6 +169,9 @@ int cilqr_create(const cilqr_params* p, int max_batch, int max_horizon, int max_
   if (err == hipSuccess) err = dmalloc(&h->d_ws, cilqr::solve_groups_ws_doubles(max_batch, max_horizon));
   if (err == hipSuccess) err = dmalloc(&h->d_redo, B);
   if (err == hipSuccess) err = dmalloc(&h->d_pair, (size_t)2);
+  if (err == hipSuccess) err = dmalloc(&h->d_triple, (size_t)3);
+  if (err == hipSuccess) err = dmalloc(&h->d_gather, (size_t)3);
+  h->comm_ranks = 1;
   if (err == hipSuccess) err = dmalloc(&h->d_oob, (size_t)1);
   if (err == hipSuccess) err = dmalloc(&h->d_occ_steps, (size_t)8 * 128);
   if (err != hipSuccess) {
@@ -201,7 +187,8 @@ int cilqr_destroy(cilqr_handle* h) {
   if (!h) return CILQR_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void* ptrs[] = {h->d_x0, h->d_U, h->d_poly, h->d_xplan, h->d_obs_pose, h->d_obs_dim, h->d_obs_w, h->d_samp_off, h->d_X, h->d_J,
+  (void)cilqr_comm_destroy(h);
+  void* ptrs[] = {h->d_triple, h->d_gather, h->d_x0, h->d_U, h->d_poly, h->d_xplan, h->d_obs_pose, h->d_obs_dim, h->d_obs_w, h->d_samp_off, h->d_X, h->d_J,
                   h->d_iters, h->d_status, h->d_obs_tab, h->d_ws, h->d_redo, h->d_pair, h->d_src, h->d_dst, h->d_bbox, h->d_oob, h->d_occ_steps};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -213,6 +200,12 @@ int cilqr_destroy(cilqr_handle* h) {
 int cilqr_set_diag_buffer(cilqr_handle* h, uint64_t* dev_buf) {
   if (!h) return fail(CILQR_ERR_ARG, "null handle");
   h->diag = (unsigned long long*)dev_buf;
+  return CILQR_OK;
+}
+
+int cilqr_set_pass_count_buffer(cilqr_handle* h, int32_t* dev_buf) {
+  if (!h) return fail(CILQR_ERR_ARG, "null handle");
+  h->passes = dev_buf;
   return CILQR_OK;
 }
 
@@ -269,6 +262,7 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
   a.obs_tab = h->d_obs_tab;
   a.redo = h->d_redo;
   a.diag = h->diag;
+  a.passes = h->passes;
   a.B = B; a.N = N; a.M = M; a.flags = flags;
   a.kp = h->kp;
   HIP_TRY(hipSetDevice(h->device));
@@ -292,9 +286,14 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
   return CILQR_OK;
 }
 
-int cilqr_solve_batch(cilqr_handle* h, int B, int N, int M, const double* x0, double* U, const double* poly,
-                      const double* xplan_fl, const double* obs_pose, const double* obs_dim, const double* obs_weight,
-                      double* X_out, double* J_out, int32_t* iters_out, int32_t* status_out, uint32_t flags) {
+}  // extern "C"
+
+namespace cilqr {
+// Host-buffer solve without the final wait: H2D of the inputs, the kernels and D2H of the results, all enqueued on the
+// handle's stream (cilqr_solve_batch = this + hipStreamSynchronize; cilqr_multi_solve_batch enqueues every device first).
+int solve_batch_enqueue(cilqr_handle* h, int B, int N, int M, const double* x0, double* U, const double* poly,
+                        const double* xplan_fl, const double* obs_pose, const double* obs_dim, const double* obs_weight,
+                        double* X_out, double* J_out, int32_t* iters_out, int32_t* status_out, uint32_t flags) {
   int rc = check_sizes(h, B, N, M);
   if (rc) return rc;
   if (B == 0) return CILQR_OK;
@@ -320,7 +319,20 @@ int cilqr_solve_batch(cilqr_handle* h, int B, int N, int M, const double* x0, do
   if (J_out) HIP_TRY(hipMemcpyAsync(J_out, h->d_J, b * sizeof(double), hipMemcpyDeviceToHost, s));
   if (iters_out) HIP_TRY(hipMemcpyAsync(iters_out, h->d_iters, b * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   if (status_out) HIP_TRY(hipMemcpyAsync(status_out, h->d_status, b * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  return CILQR_OK;
+}
+}  // namespace cilqr
+
+extern "C" {
+
+int cilqr_solve_batch(cilqr_handle* h, int B, int N, int M, const double* x0, double* U, const double* poly,
+                      const double* xplan_fl, const double* obs_pose, const double* obs_dim, const double* obs_weight,
+                      double* X_out, double* J_out, int32_t* iters_out, int32_t* status_out, uint32_t flags) {
+  int rc = cilqr::solve_batch_enqueue(h, B, N, M, x0, U, poly, xplan_fl, obs_pose, obs_dim, obs_weight, X_out, J_out, iters_out,
+                                      status_out, flags);
+  if (rc) return rc;
+  if (B == 0) return CILQR_OK;
+  HIP_TRY(hipStreamSynchronize(h->stream));
   return CILQR_OK;
 }
 
@@ -347,6 +359,7 @@ int cilqr_solve_batch_sampled_device(cilqr_handle* h, void* stream, int B, int N
   a.obs_tab = h->d_obs_tab;  // n_obs·N·8 doubles per solve ≤ the n_obs·n_samples·N·6 reserved for the materialised form
   a.redo = h->d_redo;
   a.diag = h->diag;
+  a.passes = h->passes;
   a.B = B; a.N = N; a.M = n_obs; a.flags = flags;
   a.kp = h->kp;
   HIP_TRY(hipSetDevice(h->device));
@@ -390,7 +403,7 @@ int cilqr_solve_batch_sampled(cilqr_handle* h, int B, int N, int n_obs, int n_sa
 int cilqr_argmin_device(cilqr_handle* h, void* stream, int B, const double* J, double* out_pair) {
   if (!h || !J || !out_pair || B < 1) return fail(CILQR_ERR_ARG, "cilqr_argmin_device: bad argument");
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(cilqr::launch_argmin(J, B, out_pair, nullptr, (hipStream_t)stream));
+  HIP_TRY(cilqr::launch_argmin(J, B, out_pair, nullptr, 0.0, (hipStream_t)stream));
   return CILQR_OK;
 }
 

@@ -45,6 +45,7 @@ struct SolveArgs {
   double* obs_tab;      // workspace: [B][M][N][6] (sampled: [B][M][N][8])
   int32_t* redo;        // workspace: [B] hand-over flags from the fast kernel to the general kernel
   unsigned long long* diag;  // null, or [B][8] phase cycle totals (diagnostic instantiation)
+  int32_t* passes;      // null, or [B]: backward+forward passes each solve actually executed (cilqr_set_pass_count_buffer)
   int32_t B, N, M;
   uint32_t flags;
   KParams kp;
@@ -76,8 +77,9 @@ struct LocalPlanArgs {
 hipError_t launch_local_plan(const LocalPlanArgs& a, hipStream_t stream);
 size_t local_plan_lds_bytes(int n_wpts, int cols);
 
-hipError_t launch_argmin(const double* J, int B, double* out_pair, double* scratch, hipStream_t stream);
-size_t argmin_scratch_doubles(int B);
+// Min-cost selection (cilqr_select.hip).  out_pair {J_min, index} and/or out_triple {J_min, index, offset} (either may be null).
+hipError_t launch_argmin(const double* J, int B, double* out_pair, double* out_triple, double offset, hipStream_t stream);
+hipError_t launch_select(const double* triples, int n_ranks, double* out_pair, hipStream_t stream);
 
 struct WarpArgs {
   const float* src;

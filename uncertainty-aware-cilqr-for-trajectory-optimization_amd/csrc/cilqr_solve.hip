@@ -447,7 +447,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   double* Xn = Xb;
   double* Un = Ub;
   double J_old = DBL_MAX, lamb = 1.0, J_new = 0.0;
-  int iters = 0, status = CILQR_EXIT_MAX_ITER;
+  int iters = 0, status = CILQR_EXIT_MAX_ITER, n_pass = 0;
   bool j_valid = false;  // J_new is get_J of the current (Xc, Uc)
   const bool faithful = (a.flags & CILQR_FLAG_FAITHFUL_ITERS) != 0;
   const int max_it = kp.max_iterations;
@@ -489,6 +489,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
     }
     __syncthreads();
     CILQR_STAMP(c_R)
+    ++n_pass;
     if (DIAG) ++n_R;
     if (GENERAL) {
       forward_general(kp, N, Xc, Uc, kK, Xn, Un);
@@ -530,6 +531,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   if (lane == 0) {
     if (ae.iters_out) ae.iters_out[b] = iters;
     if (ae.status_out) ae.status_out[b] = status;
+    if (ae.passes) ae.passes[b] = n_pass;
   }
   if (DIAG && lane == 0 && a.diag) {
     const unsigned long long now_ = __builtin_readcyclecounter();

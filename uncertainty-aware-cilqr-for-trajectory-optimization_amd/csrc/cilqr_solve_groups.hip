@@ -215,7 +215,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
   // ---- iteration loop, I/iLQR.cpp:204-239 (per group; groups of one wavefront diverge freely) -----------------------
   int xc = L.xa(), xn = L.xb(), uc = L.ua(), un = L.ub();
   double J_old = DBL_MAX, lamb = 1.0, J_new = 0.0;
-  int iters = 0, status = CILQR_EXIT_MAX_ITER;
+  int iters = 0, status = CILQR_EXIT_MAX_ITER, n_pass = 0;
   bool j_valid = false;
   const bool faithful = (a.flags & CILQR_FLAG_FAITHFUL_ITERS) != 0;
   const int max_it = kp.max_iterations;
@@ -359,6 +359,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
       break;
     }
     mem_sync();
+    ++n_pass;
     if (a.diag) { const unsigned long long t1 = __builtin_readcyclecounter(); tR += t1 - t0; ++nR; t0 = t1; }
 
     // ---- phase F: forward pass
@@ -510,6 +511,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
   if (g == 0) {
     if (ae.iters_out) ae.iters_out[b] = iters;
     if (ae.status_out) ae.status_out[b] = status;
+    if (ae.passes) ae.passes[b] = n_pass;
   }
 #undef XF
 #undef UF

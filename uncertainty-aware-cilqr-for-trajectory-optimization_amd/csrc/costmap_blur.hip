@@ -149,6 +149,7 @@ __device__ __forceinline__ int index_axis(double p, double map_len, double map_p
 // (rows of the ellipse's box dealt round-robin, the three sums combined by two shuffles; summation order changes by that).
 template <int LPC>
 __global__ __launch_bounds__(256) void blur_kernel(BlurArgs a) {
+#pragma clang fp contract(off)  // cell centres, the inside test and the weights as the reference's compiler forms them: no fma
   const long n = (long)a.g.rows * a.g.cols;
   const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long lin = tid / LPC;

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(NTHREADS) void warp_kernel(WarpArgs a, int tiles_i,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = ti * TILE_I + lane;
   const int drows = a.dg.rows, dcols = a.dg.cols;
-  if (i >= drows) return;
+  const bool in_i = i < drows;  // lanes past the last row stay in the wavefront for the shuffle reduction below, idle
 
   const double off_dx = 0.5 * a.dg.len_x - 0.5 * a.dg.res, off_dy = 0.5 * a.dg.len_y - 0.5 * a.dg.res;
   const double Cx = (a.dg.pos_x + off_dx) + a.dg.res * (double)(-i);
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(NTHREADS) void warp_kernel(WarpArgs a, int tiles_i,
 #pragma unroll
   for (int jj = 0; jj < TILE_J / 4; ++jj) {
     const int j = tj * TILE_J + wave + 4 * jj;
-    if (j >= dcols) break;
+    if (j >= dcols || !in_i) break;
     const double Cy = (a.dg.pos_y + off_dy) + a.dg.res * (double)(-j);
     const double x_og = (cxc - Cy * a.sin_t) + a.vx;
     const double y_og = (cxs + Cy * a.cos_t) + a.vy;
@@ -97,47 +97,6 @@ hipError_t launch_warp(const WarpArgs& a, hipStream_t stream) {
   const int n_tiles = tiles_i * tiles_j;
   if (n_tiles <= 0) return hipSuccess;
   hipLaunchKernelGGL(warp_kernel, dim3(n_tiles), dim3(NTHREADS), 0, stream, a, tiles_i, n_tiles);
-  return hipGetLastError();
-}
-
-// ---- batch min-cost selection ---------------------------------------------------------------------------------
-
-namespace {
-
-constexpr int AM_THREADS = 1024;
-
-// Lexicographic (J, index) minimum: strict-< first-minimum tie-break (I/Constraints.cpp:50 convention); NaN never wins.
-__device__ __forceinline__ void amin_merge(double& j0, int& i0, double j1, int i1) {
-  if (j1 < j0 || (j1 == j0 && i1 < i0)) { j0 = j1; i0 = i1; }
-}
-
-__global__ __launch_bounds__(AM_THREADS) void argmin_kernel(const double* J, int B, double* out_pair) {
-  __shared__ double sj[AM_THREADS / 64];
-  __shared__ int si[AM_THREADS / 64];
-  double bj = __builtin_huge_val();
-  int bi = 0x7fffffff;
-  for (int i = threadIdx.x; i < B; i += AM_THREADS) amin_merge(bj, bi, J[i], i);
-  for (int o = 32; o > 0; o >>= 1) {
-    const double oj = __shfl_xor(bj, o, 64);
-    const int oi = __shfl_xor(bi, o, 64);
-    amin_merge(bj, bi, oj, oi);
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) { sj[wave] = bj; si[wave] = bi; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < AM_THREADS / 64; ++w) amin_merge(bj, bi, sj[w], si[w]);
-    out_pair[0] = bj;
-    out_pair[1] = (bi == 0x7fffffff) ? -1.0 : (double)bi;
-  }
-}
-
-}  // namespace
-
-size_t argmin_scratch_doubles(int) { return 0; }
-
-hipError_t launch_argmin(const double* J, int B, double* out_pair, double*, hipStream_t stream) {
-  hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(AM_THREADS), 0, stream, J, B, out_pair);
   return hipGetLastError();
 }
 
