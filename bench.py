@@ -40,6 +40,20 @@ PMC_TRAFFIC_BYTES = {("c2", 1024): 2 * 5657.96e3 + 2560e3,      # profiles/r01_f
 FP64_VALU_PEAK_TF = 78.6   # vector fp64 = half the 157.3 TF fp32 vector peak of MI355X_MICROARCH.md
 
 
+_REAL_STDOUT = None
+
+
+def emit(obj):
+    """The one JSON line, on the process's original stdout."""
+    line = json.dumps(obj) + "\n"
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, line.encode())
+
+
 def cpu_rate(call, units, min_seconds=2.0, reps=3):
     """Stable CPU-baseline timing: one untimed call (starts the OpenMP pool, faults the pages in), one calibration call, then
     `reps` repetitions each looping `call` for at least `min_seconds`; returns (median units/s, relative spread, calls per rep)."""
@@ -149,7 +163,7 @@ def bench_warp(args, rank, local_rank, world, dist, dev):
                                    "sample": "the first %d frames of the pose stream, OpenMP over cells; one untimed pass, then the "
                                              "median of 3 repetitions of %d passes (>= 2 s each)" % (nf, calls)}
             out["bit_exact_vs_oracle"] = bool(np.array_equal(got, want, equal_nan=True))
-        print(json.dumps(out), flush=True)
+        emit(out)
     solver.close()
     if dist is not None:
         dist.destroy_process_group()
@@ -223,7 +237,7 @@ def bench_blur(args, rank, local_rank, world, dist, dev):
             got = out.cpu().numpy().reshape(g.cols, g.rows).T
             outj["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "frames/s", "cores": threads, "kind": "port", "sample": "one frame, OpenMP over cells"}
             outj["max_abs_diff_vs_oracle"] = float(np.nanmax(np.abs(got - want)))
-        print(json.dumps(outj), flush=True)
+        emit(outj)
     solver.close()
     if dist is not None:
         dist.destroy_process_group()
@@ -312,7 +326,7 @@ def bench_occ(args, rank, local_rank, world, dist, dev):
             cpu_s = time.perf_counter() - t1
             out["cpu_baseline"] = {"value": ns / cpu_s, "unit": "cells/s", "cores": 1, "kind": "port",
                                    "sample": "%d cells, both directions, scalar loops as in the reference" % ns}
-        print(json.dumps(out), flush=True)
+        emit(out)
     solver.close()
     if dist is not None:
         dist.destroy_process_group()
@@ -385,7 +399,7 @@ def bench_frame(args, rank, local_rank, world, dist, dev):
             out["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "frames/s", "cores": threads, "kind": "port",
                                    "sample": "one frame, OpenMP over cells (warp, blur), scalar conversion"}
             out["occupancy_cells_equal_oracle"] = float(np.mean(occ.cpu().numpy() == o))
-        print(json.dumps(out), flush=True)
+        emit(out)
     solver.close()
     if dist is not None:
         dist.destroy_process_group()
@@ -435,7 +449,7 @@ def bench_plan(args, rank, local_rank, world, dist, dev):
             out["cpu_baseline"] = {"value": ns / cpu_s, "unit": "fits/s", "cores": 1, "kind": "port",
                                    "sample": "the first %d candidates, one thread, ctypes call per fit" % ns}
             out["coefficients_bit_equal_fraction"] = float(np.mean(np.all(poly.cpu().numpy()[:ns] == want, axis=1)))
-        print(json.dumps(out), flush=True)
+        emit(out)
     solver.close()
     if dist is not None:
         dist.destroy_process_group()
@@ -511,7 +525,7 @@ def bench_c1(args, rank, local_rank, world, dist, dev):
                                    "sample": "the same scene, one thread; median of 3 repetitions of %d solves" % calls, "spread": spread}
             out["max_abs_du_vs_oracle"] = float(np.max(np.abs(got["U"] - res["w"]["U"])))
             out["iters_equal_oracle"] = bool(int(got["iters"][0]) == int(res["w"]["iters"][0]))
-        print(json.dumps(out), flush=True)
+        emit(out)
     solver.close()
     if dist is not None:
         dist.destroy_process_group()
@@ -532,6 +546,12 @@ def main():
                          "of the compact nominal + offsets form (cilqr_solve_batch_sampled_device)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line (rank 0).  Libraries underneath write there too (RCCL prints a version banner when a
+    # communicator is first made): everything but that line goes to stderr, at the file-descriptor level.
+    sys.stdout.flush()
+    global _REAL_STDOUT
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -718,7 +738,7 @@ def main():
                                    "spread": spread, "per_core": rate / threads}
             out["max_abs_du_vs_oracle"] = du
             out["iters_equal_oracle"] = bool(np.array_equal(iters.cpu().numpy()[:ns], want["iters"]))
-        print(json.dumps(out), flush=True)
+        emit(out)
     solver.close()
     if dist is not None:
         dist.destroy_process_group()

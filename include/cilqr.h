@@ -14,6 +14,7 @@
  *   iLQR::iLQR(const Parameters&)       I/iLQR.cpp:3-19         cilqr_create (+ cilqr_default_control_seq)
  *   iLQR::get_optimal_control_seq       I/iLQR.cpp:201-245      cilqr_solve_batch / cilqr_solve_batch_device
  *   iLQR::set_Obstacle / clear_Obstacle I/iLQR.cpp:20-27        obs_* arguments of cilqr_solve_batch (M = 0 ⇒ cleared)
+ *   iLQR::set_uncertainty_map / clear_uncertainty_map I/iLQR.cpp:28-35   cilqr_set_uncertainty_map(_device) / cilqr_clear_uncertainty_map
  *   Constraints::get_J                  I/Constraints.cpp:534-561   J_out of cilqr_solve_batch
  *   GridMapRosConverter::from/toOccupancyGrid G/grid_map_ros/src/GridMapRosConverter.cpp:225-307
  *                                                                cilqr_occupancy_to_layer / cilqr_layer_to_occupancy(_device)
@@ -134,6 +135,24 @@ typedef struct cilqr_map_geom {
   double pos_x, pos_y;    /* position_ (map centre in its parent frame) */
 } cilqr_map_geom;
 
+/* The costmap the uncertainty cost reads.  The reference constructs, every tick,
+ *   Uncertainty vehicle_map(params, map_msg, grid_map_msg, x_center, y_center, SIGMA_X, SIGMA_Y, SIGMA_THETA, 0, 0, nh)
+ * (I/ilqr_uncertainty_node.cpp:111-112) and hands it to iLQR::set_uncertainty_map (:113); class Uncertainty itself is ABSENT
+ * from the reference repository.  What those arguments carry is mirrored here: the blurred occupancy layer
+ * the map node publishes (grid_map_msg, layer "uncertainty_map" = output of cilqr_blur_costmap*, values 0..100, NaN unknown),
+ * its vehicle-frame geometry with the centre at (x_center, y_center) (map_param, M/src/local_costmap.cpp:793-799), and the pose
+ * of that vehicle frame in the planning frame (map_msg.info.origin = the vehicle pose at map time, :300).  The sigmas were
+ * consumed upstream by the blur.  THE ARITHMETIC OF THE COST IS DEFINED BY THIS LIBRARY (below, at
+ * cilqr_set_uncertainty_map): there is no reference arithmetic to match — parity unpinned. */
+typedef struct cilqr_uncertainty_map {
+  const float* layer;      /* rows*cols float32, column-major */
+  cilqr_map_geom geom;     /* vehicle-frame geometry of the layer */
+  double pose_x, pose_y, pose_theta; /* vehicle frame in the planning frame */
+  const double* poses;     /* NULL, or [B][3] per-solve (pose_x, pose_y, pose_theta): then the three scalars are ignored */
+  int64_t layer_stride;    /* floats from solve b's layer to solve b+1's; 0: one layer shared by the batch */
+  int32_t probes_l, probes_w; /* footprint probe grid along / across the ego heading, each >= 1 */
+} cilqr_uncertainty_map;
+
 /* --- parameters ------------------------------------------------------------------------------- */
 void cilqr_params_default(cilqr_params* p);             /* I/Parameters.cpp:3-75 + I/iLQR.cpp:17-18 */
 int  cilqr_abi_version(void);
@@ -201,6 +220,36 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
                              const double* obs_pose, const double* obs_dim, const double* obs_weight,
                              double* X_out, double* J_out, int32_t* iters_out, int32_t* status_out,
                              uint32_t flags);
+
+/* --- costmap-lookup uncertainty cost ------------------------------------------------------------------
+ * iLQR::set_uncertainty_map / clear_uncertainty_map (I/iLQR.cpp:28-35 → I/Constraints.cpp:520-528): while a map is set, every
+ * later solve on the handle adds  w_uncertainty · (vx, mx)  of the map cost to l_x, l_xx at every step, exactly where
+ * Constraints::get_state_cost does (I/Constraints.cpp:188-201); get_J is unchanged (its uncertainty term is commented out in the
+ * reference, :553-557).  The cost itself — Uncertainty::get_uncertainty_cost(state) → {x, vx(4), mx(4×4)} — has NO source in the
+ * reference; this library defines it, using only the reference's own ingredients:
+ *   footprint  probes_l × probes_w points on the rectangle safe_length × safe_width (Parameters, launch 1.1 / 0.9) centred on the
+ *              state's (x, y) and turned by its heading: body offsets a_k = -safe_length/2 + k·safe_length/(probes_l-1)
+ *              (0 when probes_l = 1), b_l likewise across;
+ *   lookup     each probe → vehicle frame (rigid transform by the map pose) → bilinear interpolation of the layer over the four
+ *              surrounding cell centres, as GridMap::atPositionLinearInterpolated does (G/grid_map_core/src/GridMap.cpp:770-837),
+ *              evaluated in double, with the interpolant's own gradient; a probe whose four cells are not all inside the map
+ *              and finite contributes nothing;
+ *   barrier    the reference's exponential barrier and Gauss-Newton form (Obstacle::barrier_function, I/Obstacle.cpp:21-32) with
+ *              c = occupancy/100 - 1:  x = q1·exp(q2·c),  vx = q2·x·∇c,  mx = q2²·x·∇c∇cᵀ,  q1 = q1_uncertainty,
+ *              q2 = q2_uncertainty (I/Parameters.cpp:41-42); ∇c is taken with respect to (x, y) only — the heading's effect on the
+ *              probe positions is ignored, as the reference ignores it for its ego circles (I/Obstacle.cpp:75-78);
+ *   result     the mean over the probes.
+ * cilqr_set_uncertainty_map_device: every pointer in *map is a device pointer that must stay valid (and is read) during later
+ * solves — e.g. the uncertainty_layer cilqr_costmap_frame_device wrote on the same stream.  cilqr_set_uncertainty_map: host
+ * pointers; one shared layer (layer_stride = 0, poses = NULL) copied into a buffer the handle owns.  Both return
+ * CILQR_ERR_ARG for probes < 1 or a bad geometry. */
+int cilqr_set_uncertainty_map_device(cilqr_handle* h, const cilqr_uncertainty_map* map);
+int cilqr_set_uncertainty_map(cilqr_handle* h, const cilqr_uncertainty_map* map);
+int cilqr_clear_uncertainty_map(cilqr_handle* h);
+
+/* Test hook: the map cost alone at n states (host buffers, [n][4]) against the map currently set (solve index 0's layer and
+ * pose) → cost[n], vx[n][2] (the x, y entries; the others are zero), mx[n][3] (xx, xy, yy). */
+int cilqr_debug_uncertainty_cost(cilqr_handle* h, int n, const double* states, double* cost, double* vx, double* mx);
 
 /* Sampled obstacles (the "uncertainty-aware" batch of BASELINE config 3: n_obs moving obstacles × n_samples Gaussian pose
  * samples, every sample an Obstacle of its own with Parameters::w_obstacle = 1/n_samples, I/Constraints.cpp:177-187).

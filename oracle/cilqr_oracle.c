@@ -269,7 +269,7 @@ void oracle_obstacle_cost(const cilqr_params* p, const double* pose, const doubl
 /* Constraints::get_state_cost, I/Constraints.cpp:145-227 with pre-built samples */
 static void state_cost_samples(const cilqr_params* p, int N, const double* X, int S, const double* sx,
                                const double* sy, int M, const double* obs_pose, const double* obs_dim,
-                               const double* obs_weight, double* l_x, double* l_xx) {
+                               const double* obs_weight, const cilqr_uncertainty_map* um, int ub, double* l_x, double* l_xx) {
   double Q[16] = {0};
   M4(Q, 0, 0) = p->w_pos;
   M4(Q, 1, 1) = p->w_pos;
@@ -291,6 +291,12 @@ static void state_cost_samples(const cilqr_params* p, int N, const double* X, in
       for (int k = 0; k < 4; k++) lxi[k] = lxi[k] + vx[k] * w;
       for (int k = 0; k < 16; k++) lxxi[k] = lxxi[k] + mx[k] * w;
     }
+    if (um) { /* :188-201; the cost itself is uncertainty_oracle.c (source absent from the reference) */
+      double ux, uvx[4], umx[16];
+      oracle_uncertainty_cost(p, um, ub, st, &ux, uvx, umx);
+      for (int k = 0; k < 4; k++) lxi[k] += uvx[k] * p->w_uncertainty;
+      for (int k = 0; k < 16; k++) lxxi[k] += umx[k] * p->w_uncertainty;
+    }
     memcpy(l_x + 4 * i, lxi, sizeof(lxi));
     memcpy(l_xx + 16 * i, lxxi, sizeof(lxxi));
   }
@@ -302,7 +308,7 @@ void oracle_state_cost(const cilqr_params* p, int N, const double* X, const doub
   const int S = p->num_of_local_wpts * 10;
   double* sx = (double*)malloc(sizeof(double) * 2 * (size_t)S);
   build_samples(p, coeffs, xplan_first, xplan_last, sx, sx + S);
-  state_cost_samples(p, N, X, S, sx, sx + S, M, obs_pose, obs_dim, obs_weight, l_x, l_xx);
+  state_cost_samples(p, N, X, S, sx, sx + S, M, obs_pose, obs_dim, obs_weight, NULL, 0, l_x, l_xx);
   free(sx);
 }
 
@@ -468,7 +474,8 @@ int oracle_quu_inverse(const double* Quu, double lamb, double* Qinv, double* eva
  * ---------------------------------------------------------------------------------------------- */
 static int backward_pass_samples(const cilqr_params* p, int N, const double* X, const double* U, int S,
                                  const double* sx, const double* sy, int M, const double* obs_pose,
-                                 const double* obs_dim, const double* obs_weight, double lamb, double* k, double* K) {
+                                 const double* obs_dim, const double* obs_weight, const cilqr_uncertainty_map* um, int ub,
+                                 double lamb, double* k, double* K) {
   double* buf = (double*)malloc(sizeof(double) * (size_t)N * (4 + 16 + 2 + 4 + 16 + 8 + 3));
   double* l_x = buf;
   double* l_xx = l_x + 4 * N;
@@ -479,7 +486,7 @@ static int backward_pass_samples(const cilqr_params* p, int N, const double* X, 
   double* vel = Bm + 8 * N;
   double* th = vel + N;
   double* acc = th + N;
-  state_cost_samples(p, N, X, S, sx, sy, M, obs_pose, obs_dim, obs_weight, l_x, l_xx);
+  state_cost_samples(p, N, X, S, sx, sy, M, obs_pose, obs_dim, obs_weight, um, ub, l_x, l_xx);
   oracle_control_cost(p, N, X, U, l_u, l_uu);
   for (int i = 0; i < N; i++) { /* :102-106: v, theta of X[:,1..N]; a = U.row(0) */
     vel[i] = X[4 * (i + 1) + 2];
@@ -572,7 +579,7 @@ int oracle_backward_pass(const cilqr_params* p, int N, const double* X, const do
   const int S = p->num_of_local_wpts * 10;
   double* sx = (double*)malloc(sizeof(double) * 2 * (size_t)S);
   build_samples(p, coeffs, xplan_first, xplan_last, sx, sx + S);
-  int ok = backward_pass_samples(p, N, X, U, S, sx, sx + S, M, obs_pose, obs_dim, obs_weight, lamb, k, K);
+  int ok = backward_pass_samples(p, N, X, U, S, sx, sx + S, M, obs_pose, obs_dim, obs_weight, NULL, 0, lamb, k, K);
   free(sx);
   return ok;
 }
@@ -597,6 +604,15 @@ void oracle_forward_pass(const cilqr_params* p, int N, const double* X, const do
 int oracle_solve(const cilqr_params* p, int N, int M, const double* x0, double* U, const double* coeffs,
                  double xplan_first, double xplan_last, const double* obs_pose, const double* obs_dim,
                  const double* obs_weight, double* X_out, double* J_out, int* status_out, double* trace) {
+  return oracle_solve_unc(p, N, M, x0, U, coeffs, xplan_first, xplan_last, obs_pose, obs_dim, obs_weight, NULL, 0, X_out, J_out,
+                          status_out, trace);
+}
+
+/* The same loop with the uncertainty map set (iLQR::set_uncertainty_map, I/iLQR.cpp:28-31): only get_state_cost changes. */
+int oracle_solve_unc(const cilqr_params* p, int N, int M, const double* x0, double* U, const double* coeffs,
+                     double xplan_first, double xplan_last, const double* obs_pose, const double* obs_dim,
+                     const double* obs_weight, const cilqr_uncertainty_map* um, int ub, double* X_out, double* J_out,
+                     int* status_out, double* trace) {
   const int S = p->num_of_local_wpts * 10;
   size_t nd = (size_t)2 * S + 4 * (N + 1) * 2 + 2 * N + 2 * N + 8 * N;
   double* buf = (double*)malloc(sizeof(double) * nd);
@@ -617,7 +633,7 @@ int oracle_solve(const cilqr_params* p, int N, int M, const double* x0, double* 
   int status = CILQR_EXIT_MAX_ITER;
   for (int i = 0; i < p->max_iterations; i++) {
     iteration_times++;
-    int ok = backward_pass_samples(p, N, X, U, S, sx, sy, M, obs_pose, obs_dim, obs_weight, lamb, k, K);
+    int ok = backward_pass_samples(p, N, X, U, S, sx, sy, M, obs_pose, obs_dim, obs_weight, um, ub, lamb, k, K);
     if (!ok) { status = CILQR_EXIT_NUMERIC; break; }
     oracle_forward_pass(p, N, X, U, k, K, X_new, U_new);
     J_new = get_J_samples(p, N, X, U, S, sx, sy); /* :217 — on the current (old) X, U */
@@ -656,6 +672,14 @@ int oracle_solve_batch(const cilqr_params* p, int B, int N, int M, const double*
                        const double* poly, const double* xplan_fl, const double* obs_pose,
                        const double* obs_dim, const double* obs_weight, double* X_out, double* J_out,
                        int* iters_out, int* status_out, int threads) {
+  return oracle_solve_batch_unc(p, B, N, M, x0, U, poly, xplan_fl, obs_pose, obs_dim, obs_weight, NULL, X_out, J_out, iters_out,
+                                status_out, threads);
+}
+
+int oracle_solve_batch_unc(const cilqr_params* p, int B, int N, int M, const double* x0, double* U,
+                           const double* poly, const double* xplan_fl, const double* obs_pose,
+                           const double* obs_dim, const double* obs_weight, const cilqr_uncertainty_map* um, double* X_out,
+                           double* J_out, int* iters_out, int* status_out, int threads) {
   if (threads < 1) threads = 1;
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic) num_threads(threads)
@@ -663,10 +687,10 @@ int oracle_solve_batch(const cilqr_params* p, int B, int N, int M, const double*
   for (int b = 0; b < B; b++) {
     int st = 0;
     double J = 0;
-    int it = oracle_solve(p, N, M, x0 + 4 * (size_t)b, U + 2 * (size_t)N * b, poly + 6 * (size_t)b,
-                          xplan_fl[2 * b], xplan_fl[2 * b + 1],
-                          M ? obs_pose + (size_t)b * M * N * 4 : NULL, M ? obs_dim + (size_t)b * M * N * 2 : NULL,
-                          obs_weight ? obs_weight + (size_t)b * M : NULL, X_out + 4 * (size_t)(N + 1) * b, &J, &st, NULL);
+    int it = oracle_solve_unc(p, N, M, x0 + 4 * (size_t)b, U + 2 * (size_t)N * b, poly + 6 * (size_t)b,
+                              xplan_fl[2 * b], xplan_fl[2 * b + 1],
+                              M ? obs_pose + (size_t)b * M * N * 4 : NULL, M ? obs_dim + (size_t)b * M * N * 2 : NULL,
+                              obs_weight ? obs_weight + (size_t)b * M : NULL, um, b, X_out + 4 * (size_t)(N + 1) * b, &J, &st, NULL);
     if (J_out) J_out[b] = J;
     if (iters_out) iters_out[b] = it;
     if (status_out) status_out[b] = st;

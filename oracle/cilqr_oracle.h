@@ -40,7 +40,7 @@ void oracle_find_closest_point(const cilqr_params* p, const double* state, const
 /* I/Obstacle.cpp:39-112 (+ barrier :21-32).  pose = relative_pos_array column, dim = dimension column. */
 void oracle_obstacle_cost(const cilqr_params* p, const double* pose, const double* dim,
                           const double* ego_state, double* vx4, double* mx16);
-/* I/Constraints.cpp:145-227 (uncertainty-map term excluded: source absent from the reference) */
+/* I/Constraints.cpp:145-227 without the uncertainty-map term (added by the *_unc entry points below) */
 void oracle_state_cost(const cilqr_params* p, int N, const double* X, const double* coeffs,
                        double xplan_first, double xplan_last, int M, const double* obs_pose,
                        const double* obs_dim, const double* obs_weight, double* l_x, double* l_xx);
@@ -70,6 +70,24 @@ void oracle_forward_pass(const cilqr_params* p, int N, const double* X, const do
 int oracle_solve(const cilqr_params* p, int N, int M, const double* x0, double* U, const double* coeffs,
                  double xplan_first, double xplan_last, const double* obs_pose, const double* obs_dim,
                  const double* obs_weight, double* X_out, double* J_out, int* status_out, double* trace);
+
+/* Costmap-lookup uncertainty cost (uncertainty_oracle.c): semantics defined by include/cilqr.h — the reference's class
+ * Uncertainty is absent from its repository, PARITY UNPINNED.  *m holds HOST pointers.  The solve adds w_uncertainty·(vx, mx)
+ * where Constraints::get_state_cost does (I/Constraints.cpp:188-201). */
+int oracle_layer_bilinear(const float* layer, const cilqr_map_geom* g, double qx, double qy, double* value, double* d_dx,
+                          double* d_dy);
+void oracle_uncertainty_cost(const cilqr_params* p, const cilqr_uncertainty_map* m, int b, const double* state, double* cost,
+                             double* vx4, double* mx16);
+/* oracle_solve / oracle_solve_batch with the map set (m may be NULL: identical to the plain calls); b = the solve's index in
+ * its batch (selects its layer and pose). */
+int oracle_solve_unc(const cilqr_params* p, int N, int M, const double* x0, double* U, const double* coeffs,
+                     double xplan_first, double xplan_last, const double* obs_pose, const double* obs_dim,
+                     const double* obs_weight, const cilqr_uncertainty_map* m, int b, double* X_out, double* J_out,
+                     int* status_out, double* trace);
+int oracle_solve_batch_unc(const cilqr_params* p, int B, int N, int M, const double* x0, double* U,
+                           const double* poly, const double* xplan_fl, const double* obs_pose,
+                           const double* obs_dim, const double* obs_weight, const cilqr_uncertainty_map* m, double* X_out,
+                           double* J_out, int* iters_out, int* status_out, int threads);
 
 /* Batch driver (layouts of include/cilqr.h), OpenMP over the batch with `threads` threads. */
 int oracle_solve_batch(const cilqr_params* p, int B, int N, int M, const double* x0, double* U,

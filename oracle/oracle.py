@@ -225,6 +225,97 @@ def layer_to_occupancy(layer, data_min, data_max):
     return out
 
 
+class UncertaintyMap(C.Structure):
+    """Mirror of `cilqr_uncertainty_map` (include/cilqr.h); HOST pointers on this side."""
+    _fields_ = [("layer", C.c_void_p), ("geom", MapGeom), ("pose_x", C.c_double), ("pose_y", C.c_double),
+                ("pose_theta", C.c_double), ("poses", C.c_void_p), ("layer_stride", C.c_int64), ("probes_l", C.c_int32),
+                ("probes_w", C.c_int32)]
+
+
+def uncertainty_map(layer, geom, pose=(0.0, 0.0, 0.0), probes=(3, 3), poses=None, batched=False):
+    """layer: (rows, cols) float32, or (B, rows, cols) with batched=True; poses: None or (B, 3).  Returns (struct, keepalive)."""
+    layer = np.asarray(layer, dtype=np.float32)
+    if batched:
+        flat = np.ascontiguousarray(np.stack([np.asfortranarray(a).flatten(order="F") for a in layer]))
+        stride = flat.shape[1]
+    else:
+        flat = np.ascontiguousarray(np.asfortranarray(layer).flatten(order="F"))
+        stride = 0
+    m = UncertaintyMap()
+    m.layer = flat.ctypes.data
+    m.geom = geom
+    m.pose_x, m.pose_y, m.pose_theta = pose
+    keep = [flat]
+    if poses is not None:
+        poses = np.ascontiguousarray(poses, dtype=np.float64)
+        m.poses = poses.ctypes.data
+        keep.append(poses)
+    m.layer_stride = stride
+    m.probes_l, m.probes_w = probes
+    return m, keep
+
+
+def layer_bilinear(layer, g, qx, qy):
+    """oracle_layer_bilinear at arrays of positions → (value, d/dx, d/dy, ok)."""
+    flat = np.ascontiguousarray(np.asfortranarray(layer, dtype=np.float32).flatten(order="F"))
+    qx = np.atleast_1d(np.asarray(qx, dtype=np.float64))
+    qy = np.atleast_1d(np.asarray(qy, dtype=np.float64))
+    v, dx, dy = np.zeros(qx.size), np.zeros(qx.size), np.zeros(qx.size)
+    ok = np.zeros(qx.size, dtype=bool)
+    a, b, c = C.c_double(0), C.c_double(0), C.c_double(0)
+    for k in range(qx.size):
+        ok[k] = bool(lib().oracle_layer_bilinear(flat.ctypes.data_as(c_float_p), C.byref(g), C.c_double(qx[k]), C.c_double(qy[k]),
+                                                 C.byref(a), C.byref(b), C.byref(c)))
+        v[k], dx[k], dy[k] = (a.value, b.value, c.value) if ok[k] else (np.nan, 0.0, 0.0)
+    return v, dx, dy, ok
+
+
+def uncertainty_cost(p, umap, states, b=0):
+    """oracle_uncertainty_cost at (n, 4) states → (cost (n,), vx (n, 4), mx (n, 4, 4))."""
+    states = np.ascontiguousarray(states, dtype=np.float64).reshape(-1, 4)
+    n = states.shape[0]
+    cost, vx, mx = np.zeros(n), np.zeros((n, 4)), np.zeros((n, 16))
+    c = C.c_double(0)
+    for k in range(n):
+        lib().oracle_uncertainty_cost(C.byref(p), C.byref(umap), int(b), _dp(states[k]), C.byref(c), _dp(vx[k]), _dp(mx[k]))
+        cost[k] = c.value
+    return cost, vx, mx.reshape(n, 4, 4)
+
+
+def solve_batch_unc(p, N, M, x0, U, poly, xplan_fl, obs_pose, obs_dim, obs_weight, umap, threads=1):
+    B = int(np.asarray(x0).reshape(-1, 4).shape[0])
+    x0 = _f64(x0)
+    U = _f64(U).copy()
+    poly = _f64(poly)
+    xplan_fl = _f64(xplan_fl)
+    obs_pose = _f64(obs_pose)
+    obs_dim = _f64(obs_dim)
+    obs_weight = _f64(obs_weight)
+    X = np.zeros((B, 4 * (N + 1)))
+    J = np.zeros(B)
+    iters = np.zeros(B, dtype=np.int32)
+    status = np.zeros(B, dtype=np.int32)
+    lib().oracle_solve_batch_unc(C.byref(p), B, N, M, _dp(x0), _dp(U), _dp(poly), _dp(xplan_fl), _dp(obs_pose),
+                                 _dp(obs_dim), _dp(obs_weight), C.byref(umap) if umap is not None else None, _dp(X), _dp(J),
+                                 iters.ctypes.data_as(c_int_p), status.ctypes.data_as(c_int_p), int(threads))
+    return dict(U=U.reshape(B, 2 * N), X=X, J=J, iters=iters, status=status)
+
+
+def ref_linear(src, geom_args, qx, qy):
+    """GridMap::atPosition(..., INTER_LINEAR) of the reference's own grid_map_core (oracle/_ref); None when not built."""
+    L = ref_lib("gridmap")
+    if L is None:
+        return None
+    src = np.asfortranarray(src, dtype=np.float32)
+    qx = np.ascontiguousarray(qx, dtype=np.float64)
+    qy = np.ascontiguousarray(qy, dtype=np.float64)
+    out = np.zeros(qx.size, dtype=np.float32)
+    ok = np.zeros(qx.size, dtype=np.int32)
+    L.ref_linear(src.ctypes.data_as(c_float_p), *[C.c_double(v) for v in geom_args], int(qx.size), _dp(qx), _dp(qy),
+                 out.ctypes.data_as(c_float_p), ok.ctypes.data_as(c_int_p))
+    return out, ok.astype(bool)
+
+
 def ref_blur(src, geom_args, sin_t, cos_t, sigma_x, sigma_y, sigma_theta, index=0):
     """The same through the reference's own grid_map_core + Eigen (oracle/_ref); None when _ref is not built."""
     L = ref_lib("gridmap")

@@ -89,6 +89,26 @@ long ref_warp(const float* src, double slx, double sly, double sres, double spx,
   return oob;
 }
 
+// GridMap::atPosition(layer, position, INTER_LINEAR) (G/grid_map_core/src/GridMap.cpp:191-201 → :770-837) at n positions of a
+// layer given as rows×cols float32 column-major.  ok[k] = 0 where the call throws.
+void ref_linear(const float* src, double lx, double ly, double res, double px, double py, int n, const double* qx,
+                const double* qy, float* out, int* ok) {
+  GridMap m;
+  m.add("layer");
+  m.setGeometry(Length(lx, ly), res, Position(px, py));
+  grid_map::Matrix& g = m["layer"];
+  for (long k = 0; k < (long)g.size(); k++) g.data()[k] = src[k];
+  for (int k = 0; k < n; k++) {
+    try {
+      out[k] = m.atPosition("layer", Position(qx[k], qy[k]), grid_map::InterpolationMethods::INTER_LINEAR);
+      ok[k] = 1;
+    } catch (const std::out_of_range&) {
+      out[k] = NAN;
+      ok[k] = 0;
+    }
+  }
+}
+
 }  // extern "C"
 
 // ---- uncertainty propagation ("blur"), M/src/arbitrary_transformation.cu:8-157 + M/include/ARBIT.cuh:51-107 ------------

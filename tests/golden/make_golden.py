@@ -4,7 +4,7 @@
     python tests/golden/make_golden.py
 
 Sources of the expected values
-  ref_params.json, ref_quu.json, ref_polyfit.json, ref_gridmap.json
+  ref_params.json, ref_quu.json, ref_polyfit.json, ref_gridmap.json, ref_blur.json, ref_gridmap_linear.json
       — produced by the REFERENCE's own code compiled in place (oracle/Makefile `make ref` → oracle/_ref/*.so):
         Parameters.cpp, the vendored Eigen 3.2.10 (EigenSolver, ColPivHouseholderQR) and grid_map_core.
   survey_known_answers.json
@@ -233,6 +233,26 @@ def gen_blur():
     dump("ref_blur.json", out)
 
 
+def gen_gridmap_linear():
+    """GridMap::atPosition(..., INTER_LINEAR) of the reference's grid_map_core at random positions: pins the lookup the
+    uncertainty cost is built on (the cost's own arithmetic has no reference source: parity unpinned)."""
+    rng = np.random.Generator(np.random.PCG64(15))
+    out = {"source": "G/grid_map_core/src/GridMap.cpp:191-201,770-837 (atPosition with INTER_LINEAR) compiled in place (oracle/_ref)",
+           "cases": []}
+    for geom in ((6.0, 4.0, 0.2, 3.0, 0.0), (5.0, 3.0, 0.1, 1.0, -0.5)):
+        g = O.map_geom(*geom)
+        src = (rng.random((g.rows, g.cols)) * 100).astype(np.float32)
+        n = 150
+        # interior positions: at least one cell away from the border (the library's own edge handling differs, see DESIGN.md)
+        qx = geom[3] + (rng.random(n) - 0.5) * (g.len_x - 4 * g.res)
+        qy = geom[4] + (rng.random(n) - 0.5) * (g.len_y - 4 * g.res)
+        val, ok = O.ref_linear(src, geom, qx, qy)
+        assert ok.all()
+        out["cases"].append(dict(geom=list(geom), shape=[g.rows, g.cols], src=[float(v) for v in src.flatten(order="F")],
+                                 qx=qx.tolist(), qy=qy.tolist(), value=[float(v) for v in val]))
+    dump("ref_gridmap_linear.json", out)
+
+
 if __name__ == "__main__":
     O.build(ref=True)
     gen_survey()
@@ -241,4 +261,5 @@ if __name__ == "__main__":
     gen_polyfit()
     gen_gridmap()
     gen_blur()
+    gen_gridmap_linear()
     gen_oracle_solves()

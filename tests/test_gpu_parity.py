@@ -1300,5 +1300,187 @@ def test_cpp_host_shards_over_all_devices(cilqr, tmp_path):
     for B in (37, 5):
         r = subprocess.run([exe, str(B)], capture_output=True, text=True)
         assert r.returncode == 0, r.stdout + r.stderr
-        out = json.loads(r.stdout)
+        out = json.loads(r.stdout.strip().splitlines()[-1])  # RCCL may print a version banner before it
         assert out["bit_equal"] and out["devices"] == n and out["best_single"] == out["best_multi"]
+
+
+# ---- costmap-lookup uncertainty cost (semantics defined by include/cilqr.h, PARITY UNPINNED) -------------------
+def _unc_layer(oracle, seed, geom=(30.0, 20.0, 0.2, 15.0, 0.0)):
+    from cilqr_amd import scenes
+    og = oracle.map_geom(*geom)
+    occ = scenes.make_occupancy(og.rows, og.cols, 90 + seed)
+    layer, _, _ = oracle.blur(np.nan_to_num(occ, nan=0.0), og, np.sin(0.1), np.cos(0.1), 0.16, 0.16, 0.017, threads=16)
+    layer[np.isnan(occ)] = np.nan
+    return geom, layer
+
+
+def _unc_params(mod, N):
+    p = mod.default_params(N)
+    p.safe_length, p.safe_width = 1.1, 0.9  # ilqr/launch/Experiment.launch:7-8
+    return p
+
+
+def test_uncertainty_cost_kernel_vs_oracle(cilqr, oracle):
+    """The map cost alone (cilqr_debug_uncertainty_cost) against the plain-C statement of the same definition: random
+    states on, beside and off the map, unknown cells, several probe grids and map poses.  Tolerance 1e-11 relative (the
+    kernel's exp is within 2 ulp of libm's)."""
+    geom, layer = _unc_layer(oracle, 0)
+    g, og = cilqr.map_geom(*geom), oracle.map_geom(*geom)
+    rng = np.random.default_rng(11)
+    for pose, probes in (((0.0, 0.0, 0.0), (3, 3)), ((2.0, -1.0, 0.3), (1, 1)), ((-40.0, 12.5, -2.1), (5, 2)), ((1.0, 1.0, 3.0), (2, 7))):
+        p, po = _unc_params(cilqr, 50), _unc_params(oracle, 50)
+        s = cilqr.Solver(p, max_batch=1, max_horizon=8, max_obstacles=0, device=0)
+        try:
+            s.set_uncertainty_map(layer, g, pose, probes)
+            q = np.stack([rng.uniform(-3, 33, 512), rng.uniform(-12, 12, 512)], 1)
+            c, sn = np.cos(pose[2]), np.sin(pose[2])
+            st = np.stack([pose[0] + c * q[:, 0] - sn * q[:, 1], pose[1] + sn * q[:, 0] + c * q[:, 1], rng.uniform(0, 8, 512),
+                           rng.uniform(-3.2, 3.2, 512)], 1)
+            cost, vx, mx = s.debug_uncertainty_cost(st)
+        finally:
+            s.close()
+        um, keep = oracle.uncertainty_map(layer, og, pose, probes)
+        wc, wv, wm = oracle.uncertainty_cost(po, um, st)
+        assert (wc > 0).mean() > 0.5 and (wc == 0).any()
+        assert np.allclose(cost, wc, rtol=1e-11, atol=1e-14)
+        assert np.allclose(vx, wv[:, :2], rtol=1e-11, atol=1e-12)
+        assert np.allclose(mx, np.stack([wm[:, 0, 0], wm[:, 0, 1], wm[:, 1, 1]], 1), rtol=1e-11, atol=1e-12)
+
+
+@pytest.mark.parametrize("G", [0, 8])
+def test_solve_with_uncertainty_map_matches_oracle(cilqr, oracle, G, monkeypatch):
+    """Whole solves with the map set (iLQR::set_uncertainty_map → w_uncertainty·(vx, mx) into l_x, l_xx at every step,
+    I/Constraints.cpp:188-201), both kernel families, shared map: U within 1e-9 of the oracle, iterations and exits equal;
+    clearing the map restores the plain solve bit for bit."""
+    from cilqr_amd import scenes
+    if G:
+        monkeypatch.setenv("CILQR_FORCE_G", str(G))
+    N, M, B = 50, 4, 192
+    p, po = _unc_params(cilqr, N), _unc_params(oracle, N)
+    sc = scenes.make_static(B, N, M, p, 4311)
+    geom, layer = _unc_layer(oracle, 1)
+    g, og = cilqr.map_geom(*geom), oracle.map_geom(*geom)
+    pose = (-1.0, 0.4, 0.05)
+    s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M, device=0)
+    try:
+        plain = _gpu_batch(s, sc)
+        s.set_uncertainty_map(layer, g, pose, (3, 3))
+        got = _gpu_batch(s, sc)
+        s.clear_uncertainty_map()
+        plain2 = _gpu_batch(s, sc)
+    finally:
+        s.close()
+    um, keep = oracle.uncertainty_map(layer, og, pose, (3, 3))
+    want = oracle.solve_batch_unc(po, N, M, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"], None, um,
+                                  threads=min(16, oracle.max_threads()))
+    _compare(got, want, TIGHT, "uncertainty map G=%d" % G)
+    for k in ("U", "X", "J", "iters", "status"):
+        assert np.array_equal(plain[k], plain2[k]), k
+    assert np.abs(got["U"] - plain["U"]).max() > 1e-3  # the map term is live
+
+
+def test_solve_with_per_solve_maps_and_poses(cilqr, oracle):
+    """The device form with one layer and one map pose per solve (a scenario batch), wavefront family and sampled obstacles
+    on top: every solve reads its own map."""
+    import torch
+    from cilqr_amd import scenes
+    N, B = 50, 48
+    p, po = _unc_params(cilqr, N), _unc_params(oracle, N)
+    sc = scenes.make_c3(B, p, n_dyn=3, n_samples=4)
+    geom = (30.0, 20.0, 0.2, 15.0, 0.0)
+    g, og = cilqr.map_geom(*geom), oracle.map_geom(*geom)
+    layers = np.stack([_unc_layer(oracle, 10 + (b % 4))[1] for b in range(B)])
+    rng = np.random.default_rng(23)
+    poses = np.stack([rng.uniform(-2, 1, B), rng.uniform(-1, 1, B), rng.uniform(-0.1, 0.1, B)], 1)
+    dev = torch.device("cuda", 0)
+    flat = np.ascontiguousarray(np.stack([np.asfortranarray(a).flatten(order="F") for a in layers]))
+    d_layers = torch.from_numpy(flat).to(dev)
+    d_poses = torch.from_numpy(poses).to(dev)
+    s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=sc["M"], device=0)
+    try:
+        s.set_uncertainty_map_device(d_layers.data_ptr(), g, (0.0, 0.0, 0.0), (2, 3), layer_stride=flat.shape[1], poses_ptr=d_poses.data_ptr())
+        got = s.solve_batch_sampled(N, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["nom_pose"], sc["nom_dim"], sc["offsets"],
+                                    sc["sample_weight"])
+        gotm = s.solve_batch(N, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"], sc["obs_weight"])
+    finally:
+        s.close()
+    um, keep = oracle.uncertainty_map(layers, og, (0.0, 0.0, 0.0), (2, 3), poses=poses, batched=True)
+    want = oracle.solve_batch_unc(po, N, sc["M"], sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"],
+                                  sc["obs_weight"], um, threads=min(16, oracle.max_threads()))
+    _compare(gotm, want, TIGHT, "per-solve maps, materialised obstacles")
+    _compare(got, want, 1e-8, "per-solve maps, sampled obstacles")
+
+
+def test_frame_then_solve_on_one_stream(cilqr, oracle):
+    """The deployed sequence on ONE stream with nothing leaving the device in between: map node's frame
+    (cilqr_costmap_frame_device: warp → blur) → its uncertainty layer set as the planner's map → batched solve.  The oracle
+    is given the layer the device produced (the frame's own parity is test_costmap_frame_equals_its_three_steps)."""
+    import torch
+    from cilqr_amd import scenes
+    N, M, B = 50, 2, 64
+    p, po = _unc_params(cilqr, N), _unc_params(oracle, N)
+    sc = scenes.make_static(B, N, M, p, 977)
+    sgeo, vgeo = (120.0, 120.0, 0.2, 10.0, 0.0), (30.0, 20.0, 0.2, 15.0, 0.0)
+    sg, vg, ovg = cilqr.map_geom(*sgeo), cilqr.map_geom(*vgeo), oracle.map_geom(*vgeo)
+    glob = scenes.make_occupancy(sg.rows, sg.cols, 5, n_blobs=250, nan_frac=0.0)
+    pose = (0.5, -0.3, 0.08)
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream(device=dev)
+    d_glob = torch.from_numpy(np.ascontiguousarray(glob.T)).to(dev)
+    veh = torch.zeros(vg.rows * vg.cols, dtype=torch.float32, device=dev)
+    unc = torch.zeros_like(veh)
+    t = {k: torch.from_numpy(np.ascontiguousarray(sc[k])).to(dev) for k in ("x0", "U", "poly", "xplan_fl", "obs_pose", "obs_dim")}
+    X = torch.zeros(B, 4 * (N + 1), dtype=torch.float64, device=dev)
+    J = torch.zeros(B, dtype=torch.float64, device=dev)
+    it = torch.zeros(B, dtype=torch.int32, device=dev)
+    st = torch.zeros(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M, device=0)
+    try:
+        s.costmap_frame_device(side.cuda_stream, d_glob.data_ptr(), sg, vg, *pose, 0.16, 0.16, 0.017, veh.data_ptr(), unc.data_ptr())
+        s.set_uncertainty_map_device(unc.data_ptr(), vg, pose, (3, 3))
+        s.solve_batch_device(side.cuda_stream, B, N, M, t["x0"].data_ptr(), t["U"].data_ptr(), t["poly"].data_ptr(), t["xplan_fl"].data_ptr(),
+                             t["obs_pose"].data_ptr(), t["obs_dim"].data_ptr(), 0, X.data_ptr(), J.data_ptr(), it.data_ptr(), st.data_ptr())
+        side.synchronize()
+    finally:
+        s.close()
+    layer = unc.cpu().numpy().reshape(vg.cols, vg.rows).T
+    assert np.nanmax(layer) > 50  # the frame did put obstacles under the planner
+    um, keep = oracle.uncertainty_map(layer, ovg, pose, (3, 3))
+    want = oracle.solve_batch_unc(po, N, M, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"], None, um,
+                                  threads=min(16, oracle.max_threads()))
+    got = dict(U=t["U"].cpu().numpy(), X=X.cpu().numpy(), J=J.cpu().numpy(), iters=it.cpu().numpy(), status=st.cpu().numpy())
+    _compare(got, want, TIGHT, "frame -> solve")
+
+
+def test_cpp_adapter_uncertainty_map(cilqr, oracle, tmp_path):
+    """iLQR::set_uncertainty_map / clear_uncertainty_map of the C++ façade, in the reference node's order (set map, set plan,
+    run_step; I/ilqr_uncertainty_node.cpp:111-119), against the oracle."""
+    import json
+    import os
+    import subprocess
+    from conftest import PKG, ROOT
+    from cilqr_amd import scenes
+    exe = str(tmp_path / "adapter_uncertainty")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "host"), "-o", exe,
+                    os.path.join(ROOT, "tests", "cpp", "adapter_uncertainty.cpp"), "-L" + os.path.join(PKG, "lib"), "-lcilqr_hip",
+                    "-Wl,-rpath," + os.path.join(PKG, "lib")], check=True)
+    geom, layer = _unc_layer(oracle, 2)
+    og = oracle.map_geom(*geom)
+    path = tmp_path / "layer.bin"
+    np.asfortranarray(layer).flatten(order="F").astype(np.float32).tofile(path)
+    pose = (-0.5, 0.2, 0.03)
+    r = subprocess.run([exe, str(path), str(og.rows), str(og.cols)] + [repr(v) for v in geom] + [repr(v) for v in pose],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    N, M = 50, 4
+    po = _unc_params(oracle, N)
+    sc = scenes.known_answer_scene(N, M, po, local_plan=oracle.local_plan)
+    um, keep = oracle.uncertainty_map(layer, og, pose, (3, 3))
+    w_on = oracle.solve_batch_unc(po, N, M, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"], None, um)
+    w_off = oracle.solve_batch_unc(po, N, M, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"], None, None)
+    assert out["with_map"]["iterations"] == int(w_on["iters"][0]) and out["cleared"]["iterations"] == int(w_off["iters"][0])
+    assert np.max(np.abs(np.array(out["with_map"]["U"]) - w_on["U"][0])) < TIGHT
+    assert np.max(np.abs(np.array(out["cleared"]["U"]) - w_off["U"][0])) < TIGHT
+    assert np.max(np.abs(w_on["U"] - w_off["U"])) > 1e-3

@@ -23,6 +23,7 @@ ABI_SYMBOLS = (
     "cilqr_argmin_device", "cilqr_wait", "cilqr_set_diag_buffer", "cilqr_set_pass_count_buffer", "cilqr_debug_quu_inverse", "cilqr_debug_blur_ellipse", "cilqr_warp_costmap", "cilqr_warp_costmap_device", "cilqr_blur_costmap", "cilqr_blur_costmap_device", "cilqr_map_geom_set",
     "cilqr_occupancy_to_layer", "cilqr_occupancy_to_layer_device", "cilqr_layer_to_occupancy", "cilqr_layer_to_occupancy_device",
     "cilqr_costmap_frame_device",
+    "cilqr_set_uncertainty_map", "cilqr_set_uncertainty_map_device", "cilqr_clear_uncertainty_map", "cilqr_debug_uncertainty_cost",
     "cilqr_comm_unique_id", "cilqr_comm_init_rank", "cilqr_comm_destroy", "cilqr_comm_size", "cilqr_argmin_global_device", "cilqr_debug_select",
     "cilqr_create_multi", "cilqr_multi_destroy", "cilqr_multi_device_count", "cilqr_multi_handle", "cilqr_multi_solve_batch",
 )
@@ -52,6 +53,13 @@ class MapGeom(C.Structure):
     """`cilqr_map_geom` — geometry of a grid_map layer."""
     _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("res", C.c_double), ("len_x", C.c_double),
                 ("len_y", C.c_double), ("pos_x", C.c_double), ("pos_y", C.c_double)]
+
+
+class UncertaintyMap(C.Structure):
+    """`cilqr_uncertainty_map` — what the reference's (absent) Uncertainty object is constructed from."""
+    _fields_ = [("layer", C.c_void_p), ("geom", MapGeom), ("pose_x", C.c_double), ("pose_y", C.c_double),
+                ("pose_theta", C.c_double), ("poses", C.c_void_p), ("layer_stride", C.c_int64), ("probes_l", C.c_int32),
+                ("probes_w", C.c_int32)]
 
 
 class CilqrError(RuntimeError):
@@ -244,6 +252,39 @@ class Solver:
 
     def argmin_device(self, stream, B, J, out_pair):
         _check(lib().cilqr_argmin_device(self._h, _vp(stream), int(B), _vp(J), _vp(out_pair)))
+
+    # ---- costmap-lookup uncertainty cost (iLQR::set_uncertainty_map / clear_uncertainty_map) ----
+    def set_uncertainty_map(self, layer, geom, pose=(0.0, 0.0, 0.0), probes=(3, 3)):
+        """layer: (rows, cols) float32 host array (the blurred occupancy); copied into a device buffer the handle owns."""
+        flat = np.ascontiguousarray(np.asfortranarray(layer, dtype=np.float32).flatten(order="F"))
+        assert flat.size == geom.rows * geom.cols
+        m = UncertaintyMap()
+        m.layer = flat.ctypes.data
+        m.geom = geom
+        m.pose_x, m.pose_y, m.pose_theta = pose
+        m.probes_l, m.probes_w = probes
+        _check(lib().cilqr_set_uncertainty_map(self._h, C.byref(m)))
+
+    def set_uncertainty_map_device(self, layer_ptr, geom, pose=(0.0, 0.0, 0.0), probes=(3, 3), layer_stride=0, poses_ptr=0):
+        """layer_ptr / poses_ptr: device addresses that stay valid while solves run (e.g. the blur kernel's output)."""
+        m = UncertaintyMap()
+        m.layer = int(layer_ptr)
+        m.geom = geom
+        m.pose_x, m.pose_y, m.pose_theta = pose
+        m.poses = int(poses_ptr) if poses_ptr else None
+        m.layer_stride = int(layer_stride)
+        m.probes_l, m.probes_w = probes
+        _check(lib().cilqr_set_uncertainty_map_device(self._h, C.byref(m)))
+
+    def clear_uncertainty_map(self):
+        _check(lib().cilqr_clear_uncertainty_map(self._h))
+
+    def debug_uncertainty_cost(self, states):
+        states = _np64(states).reshape(-1, 4)
+        n = states.shape[0]
+        cost, vx, mx = np.zeros(n), np.zeros((n, 2)), np.zeros((n, 3))
+        _check(lib().cilqr_debug_uncertainty_cost(self._h, n, _p(states), _p(cost), _p(vx), _p(mx)))
+        return cost, vx, mx
 
     # ---- cross-GPU exchange step (RCCL behind the C-ABI) ----
     def comm_init_rank(self, n_ranks, rank, id_bytes):

@@ -148,3 +148,16 @@ def make_c4(seed=SEED0 + 4, size=1024):
     poses = np.stack([20.0 * np.cos(th), 20.0 * np.sin(th), th], 1)
     return dict(src=np.asfortranarray(src), src_geom=(size * 0.2, size * 0.2, 0.2, 0.0, 0.0),
                 dst_geom=(size * 0.1, size * 0.1, 0.1, 0.0, 0.0), poses=poses)
+
+
+def make_occupancy(rows, cols, seed, n_blobs=6, nan_frac=0.01):
+    """A vehicle-frame occupancy layer (float32, 0 / 100 rectangles + a few unknown cells) for the uncertainty-cost tests and
+    bench: what the map node's warp would hand to the blur."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    occ = np.zeros((rows, cols), dtype=np.float32)
+    for _ in range(n_blobs):
+        i, j = rng.integers(0, rows - 4), rng.integers(0, cols - 4)
+        h, w = rng.integers(3, max(4, rows // 6)), rng.integers(3, max(4, cols // 6))
+        occ[i:i + h, j:j + w] = 100.0
+    occ[rng.random(occ.shape) < nan_frac] = np.nan
+    return occ

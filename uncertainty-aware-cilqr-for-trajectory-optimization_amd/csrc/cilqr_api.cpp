@@ -188,7 +188,7 @@ int cilqr_destroy(cilqr_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   (void)cilqr_comm_destroy(h);
-  void* ptrs[] = {h->d_triple, h->d_gather, h->d_x0, h->d_U, h->d_poly, h->d_xplan, h->d_obs_pose, h->d_obs_dim, h->d_obs_w, h->d_samp_off, h->d_X, h->d_J,
+  void* ptrs[] = {h->d_unc_layer, h->d_triple, h->d_gather, h->d_x0, h->d_U, h->d_poly, h->d_xplan, h->d_obs_pose, h->d_obs_dim, h->d_obs_w, h->d_samp_off, h->d_X, h->d_J,
                   h->d_iters, h->d_status, h->d_obs_tab, h->d_ws, h->d_redo, h->d_pair, h->d_src, h->d_dst, h->d_bbox, h->d_oob, h->d_occ_steps};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -200,6 +200,94 @@ int cilqr_destroy(cilqr_handle* h) {
 int cilqr_set_diag_buffer(cilqr_handle* h, uint64_t* dev_buf) {
   if (!h) return fail(CILQR_ERR_ARG, "null handle");
   h->diag = (unsigned long long*)dev_buf;
+  return CILQR_OK;
+}
+
+namespace {
+// include/cilqr.h, cilqr_set_uncertainty_map: geometry and footprint constants of the map cost, formed once on the host
+int fill_unc(const cilqr_handle* h, const cilqr_uncertainty_map* m, cilqr::UncArgs& u) {
+  if (!m || !m->layer) return fail(CILQR_ERR_ARG, "cilqr_set_uncertainty_map: null map or layer");
+  const cilqr_map_geom& g = m->geom;
+  if (g.rows < 2 || g.cols < 2 || !(g.res > 0.0) || !(g.len_x > 0.0) || !(g.len_y > 0.0))
+    return fail(CILQR_ERR_ARG, "cilqr_set_uncertainty_map: bad geometry (needs at least 2x2 cells)");
+  if (m->probes_l < 1 || m->probes_w < 1 || m->probes_l > 64 || m->probes_w > 64)
+    return fail(CILQR_ERR_ARG, "cilqr_set_uncertainty_map: probes_l / probes_w must be in [1, 64]");
+  if (m->layer_stride < 0 || (m->layer_stride > 0 && m->layer_stride < (int64_t)g.rows * g.cols))
+    return fail(CILQR_ERR_ARG, "cilqr_set_uncertainty_map: layer_stride smaller than one layer");
+  const cilqr_params& p = h->params;
+  u.layer = m->layer;
+  u.poses = m->poses;
+  u.stride = m->layer_stride;
+  u.rows = g.rows; u.cols = g.cols; u.nl = m->probes_l; u.nw = m->probes_w;
+  u.x_first = g.pos_x + (0.5 * g.len_x - 0.5 * g.res);  // cell (0,0) centre, GridMapMath.cpp:114-127
+  u.y_first = g.pos_y + (0.5 * g.len_y - 0.5 * g.res);
+  u.inv_res = 1.0 / g.res;
+  u.px = m->pose_x; u.py = m->pose_y;
+  u.cp = cos(m->pose_theta);  // host libm, like the warp's pose (M/src/local_costmap.cpp:201-202)
+  u.sp = sin(m->pose_theta);
+  u.la0 = u.nl > 1 ? -0.5 * p.safe_length : 0.0;
+  u.la_step = u.nl > 1 ? p.safe_length / (double)(u.nl - 1) : 0.0;
+  u.wb0 = u.nw > 1 ? -0.5 * p.safe_width : 0.0;
+  u.wb_step = u.nw > 1 ? p.safe_width / (double)(u.nw - 1) : 0.0;
+  u.q1 = p.q1_uncertainty; u.q2 = p.q2_uncertainty;
+  u.scale = p.w_uncertainty / (double)(u.nl * u.nw);
+  return CILQR_OK;
+}
+}  // namespace
+
+int cilqr_set_uncertainty_map_device(cilqr_handle* h, const cilqr_uncertainty_map* map) {
+  if (!h) return fail(CILQR_ERR_ARG, "null handle");
+  cilqr::UncArgs u;
+  int rc = fill_unc(h, map, u);
+  if (rc) return rc;
+  h->unc = u;
+  return CILQR_OK;
+}
+
+int cilqr_set_uncertainty_map(cilqr_handle* h, const cilqr_uncertainty_map* map) {
+  if (!h) return fail(CILQR_ERR_ARG, "null handle");
+  if (map && (map->layer_stride != 0 || map->poses))
+    return fail(CILQR_ERR_ARG, "cilqr_set_uncertainty_map: the host form takes one shared layer (per-solve layers / poses: use the _device form)");
+  cilqr::UncArgs u;
+  int rc = fill_unc(h, map, u);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t n = (size_t)map->geom.rows * map->geom.cols;
+  if (n > h->unc_layer_cap) {  // grows on the first tick of a larger map only
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->d_unc_layer) HIP_TRY(hipFree(h->d_unc_layer));
+    h->d_unc_layer = nullptr; h->unc_layer_cap = 0;
+    HIP_TRY(dmalloc(&h->d_unc_layer, n));
+    h->unc_layer_cap = n;
+  }
+  // on the handle's stream: ordered before the solves of the host-buffer entry points, which use the same stream
+  HIP_TRY(hipMemcpyAsync(h->d_unc_layer, map->layer, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));  // the caller's buffer is free again, and device-pointer solves on other streams see the layer
+  u.layer = h->d_unc_layer;
+  h->unc = u;
+  return CILQR_OK;
+}
+
+int cilqr_clear_uncertainty_map(cilqr_handle* h) {
+  if (!h) return fail(CILQR_ERR_ARG, "null handle");
+  memset(&h->unc, 0, sizeof(h->unc));
+  return CILQR_OK;
+}
+
+int cilqr_debug_uncertainty_cost(cilqr_handle* h, int n, const double* states, double* cost, double* vx, double* mx) {
+  if (!h || n < 1 || !states || !cost || !vx || !mx) return fail(CILQR_ERR_ARG, "cilqr_debug_uncertainty_cost: bad argument");
+  if (!h->unc.layer) return fail(CILQR_ERR_ARG, "cilqr_debug_uncertainty_cost: no uncertainty map is set");
+  HIP_TRY(hipSetDevice(h->device));
+  double* d = nullptr;
+  HIP_TRY(dmalloc(&d, (size_t)10 * n));
+  hipError_t e = hipMemcpyAsync(d, states, sizeof(double) * 4 * n, hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) e = cilqr::launch_unc_cost(h->unc, n, d, d + 4 * (size_t)n, d + 5 * (size_t)n, d + 7 * (size_t)n, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(cost, d + 4 * (size_t)n, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(vx, d + 5 * (size_t)n, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(mx, d + 7 * (size_t)n, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(d);
+  HIP_TRY(e);
   return CILQR_OK;
 }
 
@@ -263,6 +351,7 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
   a.redo = h->d_redo;
   a.diag = h->diag;
   a.passes = h->passes;
+  a.unc = h->unc;
   a.B = B; a.N = N; a.M = M; a.flags = flags;
   a.kp = h->kp;
   HIP_TRY(hipSetDevice(h->device));
@@ -360,6 +449,7 @@ int cilqr_solve_batch_sampled_device(cilqr_handle* h, void* stream, int B, int N
   a.redo = h->d_redo;
   a.diag = h->diag;
   a.passes = h->passes;
+  a.unc = h->unc;
   a.B = B; a.N = N; a.M = n_obs; a.flags = flags;
   a.kp = h->kp;
   HIP_TRY(hipSetDevice(h->device));

@@ -45,6 +45,10 @@ struct cilqr_handle {
   unsigned occ_slot;
   unsigned long long* diag;  // caller-owned device buffer or null
   int32_t* passes;           // caller-owned device buffer or null (cilqr_set_pass_count_buffer)
+  // uncertainty map (cilqr_set_uncertainty_map*): what the kernels read, and the device copy made from a host layer
+  cilqr::UncArgs unc;
+  float* d_unc_layer;
+  size_t unc_layer_cap;
   // cross-rank min-cost exchange (cilqr_comm.cpp)
   ncclComm* comm;            // null: this handle is its own world
   int comm_ranks, comm_rank;

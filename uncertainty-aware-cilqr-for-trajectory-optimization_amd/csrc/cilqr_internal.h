@@ -27,6 +27,18 @@ struct KParams {
   int32_t n_samples;  // num_of_local_wpts * 10 (I/Constraints.cpp:28)
 };
 
+// The uncertainty map as the kernels read it (cilqr_set_uncertainty_map*, include/cilqr.h); layer == nullptr: no map set.
+struct UncArgs {
+  const float* layer;     // rows*cols float32 column-major per solve (stride floats apart; 0: shared)
+  const double* poses;    // null, or [B][3] per-solve (x, y, theta) of the vehicle frame in the planning frame
+  long long stride;
+  int32_t rows, cols, nl, nw;
+  double x_first, y_first, inv_res;  // centre of cell (0, 0) and 1/resolution (G/grid_map_core/src/GridMapMath.cpp:114-127)
+  double px, py, cp, sp;             // shared pose: position, cos and sin of its heading (host libm)
+  double la0, la_step, wb0, wb_step; // footprint probe offsets along / across the heading: la0 + k*la_step, wb0 + l*wb_step
+  double q1, q2, scale;              // barrier constants; scale = w_uncertainty / (nl*nw)
+};
+
 struct SolveArgs {
   const double* x0;
   double* U;
@@ -49,6 +61,7 @@ struct SolveArgs {
   int32_t B, N, M;
   uint32_t flags;
   KParams kp;
+  UncArgs unc;
 };
 
 // Launchers (defined in the .hip files). All are asynchronous on `stream`.
@@ -61,6 +74,8 @@ size_t solve_sampled_tab_doubles(int n_obs, int N);         // its workspace nee
 // G lanes per solve (G in {1,2,4,8,16,32}), workspace `ws` of solve_groups_ws_doubles(B, N) doubles (cilqr_solve_groups.hip).
 hipError_t launch_solve_groups(const SolveArgs& a, int G, double* ws, hipStream_t stream);
 size_t solve_groups_ws_doubles(int B, int N);
+// Test hook: the map cost alone at n states [n][4] → cost[n], vx[n][2], mx[n][3] (solve 0's layer and pose).
+hipError_t launch_unc_cost(const UncArgs& u, int n, const double* states, double* cost, double* vx, double* mx, hipStream_t stream);
 hipError_t launch_quu_inverse(int n, const double* q, const double* lamb, double* out, int general, hipStream_t stream);
 
 // Batched LocalPlanner (local_plan.hip): one lane per candidate.

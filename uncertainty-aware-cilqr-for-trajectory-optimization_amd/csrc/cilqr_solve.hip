@@ -165,7 +165,7 @@ struct SampledSource {
 template <typename Source>
 __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int lane, const double* samp, int S,
                                             const SampleGrid& grid, const double* X, const double* U, double* rec,
-                                            const Source& src) {
+                                            const Source& src, const UncProbe* unc) {
   double Jpart = 0.0;
   for (int t = lane; t < N; t += WAVE) {
     const double* xr = X + t * XR;
@@ -174,7 +174,7 @@ __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int
     const int cs = closest_sample(S, grid, px, py, LdsSamples{samp});
     Rec c;
     Jpart += lin_step<true>(kp, px, py, xr[2], xr[4], xr[5], U[2 * t], U[2 * t + 1], xn[2], xn[4], xn[5], samp[2 * cs],
-                      samp[2 * cs + 1], M, src.at(t), c);
+                      samp[2 * cs + 1], M, src.at(t), c, unc);
     double* r = rec + t * REC;
     r[0] = c.lx0; r[1] = c.lx1; r[2] = c.lx2; r[3] = c.l00; r[4] = c.l01; r[5] = c.l11;
     r[6] = c.lu0; r[7] = c.lu1; r[8] = c.luu0; r[9] = c.luu1;
@@ -349,6 +349,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   const KParams kp = a.kp;
   const int N = a.N, M = a.M, S = kp.n_samples;
   const int n_entries = TAB == 2 ? M * a.n_samples : M;  // obstacle entries per step
+  const bool has_unc = a.unc.layer != nullptr;
   if (b >= a.B) return;
   if (GENERAL && a.redo[b] == 0) return;
 
@@ -458,9 +459,15 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
     {
       double part;
       const KParams kpl = phase_params();  // phase-local read of the parameter block (cilqr_device.hpp)
+      UncProbe probe;
+      const UncProbe* unc = nullptr;
+      if (has_unc) {  // uniform: a map is set (cilqr_set_uncertainty_map*)
+        probe = make_unc_probe(phase_args().unc, b);
+        unc = &probe;
+      }
       if (TAB == 2) part = linearize(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, SampledSource{tab, off, rmax, Xc, N, a.n_samples, M, a.samp_w, kpl.ego_front, kpl.ego_rear,
-                                                     sqrt(1.0 + 64.0 / kpl.q2_front), sqrt(1.0 + 64.0 / kpl.q2_rear)});
-      else part = linearize(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, TabSource{tab, wts, N, kpl.w_obstacle});
+                                                     sqrt(1.0 + 64.0 / kpl.q2_front), sqrt(1.0 + 64.0 / kpl.q2_rear)}, unc);
+      else part = linearize(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, TabSource{tab, wts, N, kpl.w_obstacle}, unc);
       J_new = readfirstlane_f64(wave_sum(part));
     }
     j_valid = true;
@@ -553,6 +560,21 @@ __global__ void quu_inverse_kernel(int n, const double* q, const double* lamb, d
   out[4 * i] = ok ? i00 : nan; out[4 * i + 1] = ok ? i01 : nan; out[4 * i + 2] = ok ? i01 : nan; out[4 * i + 3] = ok ? i11 : nan;
 }
 
+__global__ void unc_cost_kernel(UncArgs u, int n, const double* states, double* cost, double* vx, double* mx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const UncProbe q = make_unc_probe(u, 0);
+  const double* st = states + 4 * (size_t)i;
+  double sn, cs;
+  sincos_fast(st[3], &sn, &cs);
+  double g0 = 0.0, g1 = 0.0, h00 = 0.0, h01 = 0.0, h11 = 0.0;
+  const double c = q(st[0], st[1], cs, sn, g0, g1, h00, h01, h11);
+  const double inv = q.scale != 0.0 ? 1.0 / (q.scale * (double)(q.nl * q.nw)) : 0.0;  // undo w_uncertainty: report the bare cost terms
+  cost[i] = c;
+  vx[2 * i] = g0 * inv; vx[2 * i + 1] = g1 * inv;
+  mx[3 * i] = h00 * inv; mx[3 * i + 1] = h01 * inv; mx[3 * i + 2] = h11 * inv;
+}
+
 template <bool DIAG, int TAB>
 hipError_t launch_pair(const SolveArgs& a, size_t lds, hipStream_t stream) {
   if (lds > 64 * 1024) {  // long horizons: opt in to more than the default 64 KiB of dynamic LDS (the CU has 160 KiB)
@@ -579,6 +601,12 @@ size_t solve_sampled_lds_bytes(int n_obs, int n_samples) {
   return ((size_t)n_obs * n_samples * OFFF + (size_t)n_obs) * sizeof(double);  // offset records + rmax
 }
 size_t solve_sampled_tab_doubles(int n_obs, int N) { return (size_t)n_obs * NOMF * N; }
+
+hipError_t launch_unc_cost(const UncArgs& u, int n, const double* states, double* cost, double* vx, double* mx, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(unc_cost_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, u, n, states, cost, vx, mx);
+  return hipGetLastError();
+}
 
 hipError_t launch_quu_inverse(int n, const double* q, const double* lamb, double* out, int general, hipStream_t stream) {
   if (n <= 0) return hipSuccess;

@@ -240,6 +240,12 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
         o.vn = xq[2 * S]; o.cn = xq[4 * S]; o.sn = xq[5 * S];
       };
       const KParams kpl = phase_params();  // this phase's own read of the parameter block (cilqr_device.hpp)
+      UncProbe probe;
+      const UncProbe* unc = nullptr;
+      if (aq->unc.layer) {  // a map is set (cilqr_set_uncertainty_map*): the same for every solve of the launch
+        probe = make_unc_probe(aq->unc, b);
+        unc = &probe;
+      }
       LIn cur, nxt;
       if (g < N) load_in(cur, g);
       for (int t = g; t < N; t += G) {
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_kernel(SolveArgs a, d
           return true;
         };
         Rec c;
-        Jpart += lin_step(kpl, cur.px, cur.py, cur.v, cur.ct, cur.st, cur.u0, cur.u1, cur.vn, cur.cn, cur.sn, cx, cy, M, obs, c);
+        Jpart += lin_step(kpl, cur.px, cur.py, cur.v, cur.ct, cur.st, cur.u0, cur.u1, cur.vn, cur.cn, cur.sn, cx, cy, M, obs, c, unc);
         double* r = &RF(t, 0);
         r[0] = c.lx0; r[S] = c.lx1; r[2 * S] = c.lx2; r[3 * S] = c.l00; r[4 * S] = c.l01; r[5 * S] = c.l11;
         r[6 * S] = c.lu0; r[7 * S] = c.lu1; r[8 * S] = c.luu0; r[9 * S] = c.luu1;

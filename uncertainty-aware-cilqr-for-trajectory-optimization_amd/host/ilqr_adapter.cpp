@@ -45,6 +45,20 @@ void iLQR::clear_Obstacle() {
   obs_dim_.clear();
 }
 
+void iLQR::set_uncertainty_map(const Uncertainty& u) {
+  if (u.layer.size() != (size_t)u.geom.rows * u.geom.cols) throw std::runtime_error("set_uncertainty_map: layer size does not match its geometry");
+  cilqr_uncertainty_map m{};
+  m.layer = u.layer.data();
+  m.geom = u.geom;
+  m.pose_x = u.pose_x; m.pose_y = u.pose_y; m.pose_theta = u.pose_theta;
+  m.poses = nullptr;
+  m.layer_stride = 0;
+  m.probes_l = u.probes_l; m.probes_w = u.probes_w;
+  check(cilqr_set_uncertainty_map(h_, &m), "cilqr_set_uncertainty_map");
+}
+
+void iLQR::clear_uncertainty_map() { check(cilqr_clear_uncertainty_map(h_), "cilqr_clear_uncertainty_map"); }
+
 void iLQR::set_global_plan(const Matrix& global_plan) {
   if (global_plan.rows != 2 || global_plan.cols < 1) throw std::runtime_error("set_global_plan: expected a 2×P matrix");
   global_plan_ = global_plan;

@@ -10,8 +10,10 @@
 // Differences from the reference interface, all forced by the boundary:
 //   * Eigen types are replaced by the column-major `Matrix` below (Eigen is not a dependency of this library);
 //   * device/HIP failures throw std::runtime_error (the reference solver cannot fail that way);
-//   * set_uncertainty_map is absent: the reference's Uncertainty class is not in its repository;
-//     clear_uncertainty_map() exists and is a no-op so node code that calls it still compiles;
+//   * the reference's Uncertainty class is not in its repository: the `Uncertainty` below carries what its
+//     constructor is given at the call site (I/ilqr_uncertainty_node.cpp:111-112) and the cost is the one include/cilqr.h
+//     defines at cilqr_set_uncertainty_map (parity unpinned); set_uncertainty_map / clear_uncertainty_map keep the
+//     reference's names and effect (I/iLQR.cpp:28-35);
 //   * nothing is printed to stdout (the reference prints three lines per solve, I/iLQR.cpp:240-242); the same facts are
 //     available as last_iterations / last_exit / last_cost.
 #pragma once
@@ -45,6 +47,17 @@ class Obstacle {
   Matrix relative_pos_array;  // 4 × horizon: (x, y, v, theta) per step
 };
 
+// What the reference node builds its Uncertainty object from, every tick (I/ilqr_uncertainty_node.cpp:111-112): the blurred
+// occupancy layer of the map node (grid_map_msg "uncertainty_map"; rows×cols float32 column-major, 0..100, NaN unknown), its
+// vehicle-frame geometry centred at (x_center, y_center) (map_param), and the vehicle pose the map was made at
+// (map_msg.info.origin).  probes: footprint sampling of the safe_length × safe_width rectangle (include/cilqr.h).
+struct Uncertainty {
+  std::vector<float> layer;
+  cilqr_map_geom geom{};
+  double pose_x = 0.0, pose_y = 0.0, pose_theta = 0.0;
+  int probes_l = 3, probes_w = 3;
+};
+
 // vehiclepub/Experiment as the node fills it (I/ilqr_uncertainty_node.cpp:243-284): start_pos[4], X flattened column by
 // column (4 per step, horizon + 1 steps), U likewise (2 per step), planning_time in seconds.  (Its ros::Time start_time
 // belongs to the caller.)  Column-major flattening is the memory order of X_result / U_result, so these are copies.
@@ -64,7 +77,8 @@ class iLQR {
 
   void set_Obstacle(const std::vector<Obstacle>& obstacles);  // I/iLQR.cpp:20-23 (deep copy, like the reference)
   void clear_Obstacle();                                      // :24-27
-  void clear_uncertainty_map() {}                             // :32-35 (see header comment)
+  void set_uncertainty_map(const Uncertainty& uncertainty);    // :28-31 → Constraints::set_uncertainty_map (I/Constraints.cpp:520-524)
+  void clear_uncertainty_map();                               // :32-35
   void set_global_plan(const Matrix& global_plan);            // :41-45, 2 × P waypoints
 
   // I/iLQR.cpp:201-245.  U is the warm start on entry and U_result on return; x_local_plan is the local plan's x row
