@@ -190,7 +190,14 @@ int cilqr_create(const cilqr_params* p, int max_batch, int max_horizon, int max_
                  cilqr_handle** out);
 int cilqr_destroy(cilqr_handle* h);
 
+/* Page-locked host memory for the buffers handed to the host-buffer entry points: from such memory their copies are
+ * asynchronous DMA transfers; any other host memory works too (the HIP runtime then stages each copy).  Returns NULL on failure. */
+void* cilqr_host_alloc(size_t bytes);
+int   cilqr_host_free(void* p);
+
 /* Batched iLQR::get_optimal_control_seq (I/iLQR.cpp:201-245) — host buffers, synchronous.
+ * Nothing is allocated per call: the device arena and a pinned staging buffer are sized at cilqr_create.  A call whose arrays
+ * total ≤ 1 MiB (the drop-in B = 1 tick, a handful of candidates) travels as one packed host→device and one device→host copy.
  *   x0        [B][4]            ego state (x, y, v, theta)
  *   U         [B][2*N]  in/out  warm start in, U_result out (I/iLQR.cpp:222,244)
  *   poly      [B][6]            poly_coeffs, ascending powers

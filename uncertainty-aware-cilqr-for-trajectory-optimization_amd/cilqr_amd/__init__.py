@@ -19,7 +19,7 @@ EXIT_TOLERANCE, EXIT_LAMBDA_MAX, EXIT_MAX_ITER, EXIT_NUMERIC = 0, 1, 2, 3
 # every symbol include/cilqr.h declares
 ABI_SYMBOLS = (
     "cilqr_params_default", "cilqr_abi_version", "cilqr_device_count", "cilqr_last_error", "cilqr_default_control_seq",
-    "cilqr_local_plan", "cilqr_local_plan_batch", "cilqr_local_plan_batch_device", "cilqr_create", "cilqr_destroy", "cilqr_solve_batch", "cilqr_solve_batch_device", "cilqr_solve_batch_sampled", "cilqr_solve_batch_sampled_device",
+    "cilqr_local_plan", "cilqr_local_plan_batch", "cilqr_local_plan_batch_device", "cilqr_create", "cilqr_destroy", "cilqr_host_alloc", "cilqr_host_free", "cilqr_solve_batch", "cilqr_solve_batch_device", "cilqr_solve_batch_sampled", "cilqr_solve_batch_sampled_device",
     "cilqr_argmin_device", "cilqr_wait", "cilqr_set_diag_buffer", "cilqr_set_pass_count_buffer", "cilqr_debug_quu_inverse", "cilqr_debug_blur_ellipse", "cilqr_warp_costmap", "cilqr_warp_costmap_device", "cilqr_blur_costmap", "cilqr_blur_costmap_device", "cilqr_map_geom_set",
     "cilqr_occupancy_to_layer", "cilqr_occupancy_to_layer_device", "cilqr_layer_to_occupancy", "cilqr_layer_to_occupancy_device",
     "cilqr_costmap_frame_device",
@@ -91,6 +91,26 @@ def comm_unique_id():
     buf = (C.c_char * COMM_ID_BYTES)()
     _check(lib().cilqr_comm_unique_id(buf))
     return bytes(buf.raw)
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """A numpy array over page-locked memory from `cilqr_host_alloc` (never freed: keep and reuse it)."""
+    L = lib()
+    L.cilqr_host_alloc.restype = C.c_void_p
+    L.cilqr_host_alloc.argtypes = [C.c_size_t]
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = L.cilqr_host_alloc(max(n, 1))
+    if not p:
+        raise CilqrError("cilqr_host_alloc failed: %s" % L.cilqr_last_error().decode())
+    buf = (C.c_char * max(n, 1)).from_address(p)
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
+def pinned_copy(a):
+    a = np.ascontiguousarray(a)
+    out = pinned_empty(a.shape, a.dtype)
+    out[...] = a
+    return out
 
 
 def _check(rc):
@@ -165,10 +185,12 @@ class Solver:
             pass
 
     # ---- host-buffer entry point (synchronous) ----
-    def solve_batch(self, N, x0, U, poly, xplan_fl, obs_pose=None, obs_dim=None, obs_weight=None, flags=0):
+    def solve_batch(self, N, x0, U, poly, xplan_fl, obs_pose=None, obs_dim=None, obs_weight=None, flags=0, out=None):
+        """out: optional dict of preallocated arrays U (in/out: holds the warm start), X, J, iters, status — e.g. over pinned
+        memory (`pinned_empty`); then U is used in place instead of being copied."""
         x0 = _np64(x0).reshape(-1, 4)
         B = x0.shape[0]
-        U = _np64(U).reshape(B, 2 * N).copy()
+        U = _np64(U).reshape(B, 2 * N).copy() if out is None else out["U"]
         poly = _np64(poly).reshape(B, POLY)
         xplan_fl = _np64(xplan_fl).reshape(B, 2)
         M = 0
@@ -178,10 +200,11 @@ class Solver:
             obs_dim = _np64(obs_dim).reshape(B, M, 2 * N)
             if obs_weight is not None:
                 obs_weight = _np64(obs_weight).reshape(B, M)
-        X = np.zeros((B, 4 * (N + 1)))
-        J = np.zeros(B)
-        iters = np.zeros(B, dtype=np.int32)
-        status = np.zeros(B, dtype=np.int32)
+        if out is None:
+            X, J = np.zeros((B, 4 * (N + 1))), np.zeros(B)
+            iters, status = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        else:
+            X, J, iters, status = out["X"], out["J"], out["iters"], out["status"]
         _check(lib().cilqr_solve_batch(self._h, B, int(N), int(M), _p(x0), _p(U), _p(poly), _p(xplan_fl), _p(obs_pose),
                                        _p(obs_dim), _p(obs_weight), _p(X), _p(J), _p(iters, _ip), _p(status, _ip),
                                        C.c_uint32(flags)))

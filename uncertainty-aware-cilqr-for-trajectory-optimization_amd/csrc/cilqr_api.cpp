@@ -152,18 +152,13 @@ int cilqr_create(const cilqr_params* p, int max_batch, int max_horizon, int max_
   if (const char* fg = getenv("CILQR_FORCE_G")) h->force_g = atoi(fg);
   const size_t B = max_batch, N = max_horizon, M = max_obstacles;
   hipError_t err = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-  if (err == hipSuccess) err = dmalloc(&h->d_x0, B * 4);
-  if (err == hipSuccess) err = dmalloc(&h->d_U, B * 2 * N);
-  if (err == hipSuccess) err = dmalloc(&h->d_poly, B * CILQR_POLY_COEFFS);
-  if (err == hipSuccess) err = dmalloc(&h->d_xplan, B * 2);
-  if (err == hipSuccess) err = dmalloc(&h->d_obs_pose, B * M * N * 4);
-  if (err == hipSuccess) err = dmalloc(&h->d_obs_dim, B * M * N * 2);
-  if (err == hipSuccess) err = dmalloc(&h->d_obs_w, B * M);
-  if (err == hipSuccess) err = dmalloc(&h->d_samp_off, B * M * 3);
-  if (err == hipSuccess) err = dmalloc(&h->d_X, B * 4 * (N + 1));
-  if (err == hipSuccess) err = dmalloc(&h->d_J, B);
-  if (err == hipSuccess) err = dmalloc(&h->d_iters, B);
-  if (err == hipSuccess) err = dmalloc(&h->d_status, B);
+  {  // arena of the host-buffer entry points: the larger of the two layouts that can be asked for (cilqr_host_io.cpp)
+    const cilqr::IoLayout plain = cilqr::io_layout(B, N, M, true, 0), sampled = cilqr::io_layout(B, N, M, false, 1);
+    h->arena_cap = plain.end > sampled.end ? plain.end : sampled.end;
+    if (err == hipSuccess) err = hipMalloc((void**)&h->d_arena, h->arena_cap);
+    h->stage_cap = h->arena_cap < ((size_t)1 << 20) ? h->arena_cap : ((size_t)1 << 20);  // pinned: calls up to 1 MiB travel packed
+    if (err == hipSuccess) err = hipHostMalloc((void**)&h->stage, h->stage_cap, hipHostMallocDefault);
+  }
   const size_t Bpad = (B + 63) / 64 * 64;  // the grouped kernels pad the batch to whole wavefronts
   if (err == hipSuccess) err = dmalloc(&h->d_obs_tab, Bpad * M * N * 6);
   if (err == hipSuccess) err = dmalloc(&h->d_ws, cilqr::solve_groups_ws_doubles(max_batch, max_horizon));
@@ -174,6 +169,13 @@ int cilqr_create(const cilqr_params* p, int max_batch, int max_horizon, int max_
   h->comm_ranks = 1;
   if (err == hipSuccess) err = dmalloc(&h->d_oob, (size_t)1);
   if (err == hipSuccess) err = dmalloc(&h->d_occ_steps, (size_t)8 * 128);
+  if (err == hipSuccess) {  // scratch of cilqr_local_plan_batch for max_batch candidates and a 1024-waypoint path
+    void* unused = nullptr;
+    const size_t W = (size_t)p->num_of_local_wpts;
+    if (cilqr::scratch_bytes(h, cilqr::SCR_PLAN_IO, (B * (4 + CILQR_POLY_COEFFS + 2 + 2 * W)) * sizeof(double) + B * sizeof(int32_t), &unused) != CILQR_OK ||
+        cilqr::scratch_bytes(h, cilqr::SCR_PLAN_PATH, 2 * 1024 * sizeof(double), &unused) != CILQR_OK)
+      err = hipErrorOutOfMemory;
+  }
   if (err != hipSuccess) {
     int rc = fail(CILQR_ERR_HIP, "cilqr_create: device allocation failed: %s", hipGetErrorString(err));
     cilqr_destroy(h);
@@ -188,8 +190,10 @@ int cilqr_destroy(cilqr_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   (void)cilqr_comm_destroy(h);
-  void* ptrs[] = {h->d_unc_layer, h->d_triple, h->d_gather, h->d_x0, h->d_U, h->d_poly, h->d_xplan, h->d_obs_pose, h->d_obs_dim, h->d_obs_w, h->d_samp_off, h->d_X, h->d_J,
-                  h->d_iters, h->d_status, h->d_obs_tab, h->d_ws, h->d_redo, h->d_pair, h->d_src, h->d_dst, h->d_bbox, h->d_oob, h->d_occ_steps};
+  if (h->stage) (void)hipHostFree(h->stage);
+  for (void* p : h->scratch)
+    if (p) (void)hipFree(p);
+  void* ptrs[] = {h->d_unc_layer, h->d_triple, h->d_gather, h->d_arena, h->d_obs_tab, h->d_ws, h->d_redo, h->d_pair, h->d_src, h->d_dst, h->d_bbox, h->d_oob, h->d_occ_steps};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -278,16 +282,16 @@ int cilqr_debug_uncertainty_cost(cilqr_handle* h, int n, const double* states, d
   if (!h || n < 1 || !states || !cost || !vx || !mx) return fail(CILQR_ERR_ARG, "cilqr_debug_uncertainty_cost: bad argument");
   if (!h->unc.layer) return fail(CILQR_ERR_ARG, "cilqr_debug_uncertainty_cost: no uncertainty map is set");
   HIP_TRY(hipSetDevice(h->device));
-  double* d = nullptr;
-  HIP_TRY(dmalloc(&d, (size_t)10 * n));
-  hipError_t e = hipMemcpyAsync(d, states, sizeof(double) * 4 * n, hipMemcpyHostToDevice, h->stream);
-  if (e == hipSuccess) e = cilqr::launch_unc_cost(h->unc, n, d, d + 4 * (size_t)n, d + 5 * (size_t)n, d + 7 * (size_t)n, h->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(cost, d + 4 * (size_t)n, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(vx, d + 5 * (size_t)n, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(mx, d + 7 * (size_t)n, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  (void)hipFree(d);
-  HIP_TRY(e);
+  void* v = nullptr;
+  int rc = cilqr::scratch_bytes(h, cilqr::SCR_DEBUG, sizeof(double) * 10 * (size_t)n, &v);
+  if (rc) return rc;
+  double* d = (double*)v;
+  HIP_TRY(hipMemcpyAsync(d, states, sizeof(double) * 4 * n, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(cilqr::launch_unc_cost(h->unc, n, d, d + 4 * (size_t)n, d + 5 * (size_t)n, d + 7 * (size_t)n, h->stream));
+  HIP_TRY(hipMemcpyAsync(cost, d + 4 * (size_t)n, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(vx, d + 5 * (size_t)n, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(mx, d + 7 * (size_t)n, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   return CILQR_OK;
 }
 
@@ -300,30 +304,29 @@ int cilqr_set_pass_count_buffer(cilqr_handle* h, int32_t* dev_buf) {
 int cilqr_debug_quu_inverse(cilqr_handle* h, int n, const double* Quu, const double* lamb, double* Qinv, int general) {
   if (!h || n < 1 || !Quu || !lamb || !Qinv) return fail(CILQR_ERR_ARG, "cilqr_debug_quu_inverse: bad argument");
   HIP_TRY(hipSetDevice(h->device));
-  double *dq = nullptr, *dl = nullptr, *dout = nullptr;
-  HIP_TRY(dmalloc(&dq, (size_t)4 * n));
-  HIP_TRY(dmalloc(&dl, (size_t)n));
-  HIP_TRY(dmalloc(&dout, (size_t)4 * n));
-  HIP_TRY(hipMemcpy(dq, Quu, sizeof(double) * 4 * n, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dl, lamb, sizeof(double) * n, hipMemcpyHostToDevice));
+  void* v = nullptr;
+  int rc = cilqr::scratch_bytes(h, cilqr::SCR_DEBUG, sizeof(double) * 9 * (size_t)n, &v);
+  if (rc) return rc;
+  double *dq = (double*)v, *dl = dq + 4 * (size_t)n, *dout = dl + n;
+  HIP_TRY(hipMemcpyAsync(dq, Quu, sizeof(double) * 4 * n, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(dl, lamb, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(cilqr::launch_quu_inverse(n, dq, dl, dout, general, h->stream));
+  HIP_TRY(hipMemcpyAsync(Qinv, dout, sizeof(double) * 4 * n, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipMemcpy(Qinv, dout, sizeof(double) * 4 * n, hipMemcpyDeviceToHost));
-  (void)hipFree(dq); (void)hipFree(dl); (void)hipFree(dout);
   return CILQR_OK;
 }
 
 int cilqr_debug_blur_ellipse(cilqr_handle* h, int n, const double* abc, double* out) {
   if (!h || n < 1 || !abc || !out) return fail(CILQR_ERR_ARG, "cilqr_debug_blur_ellipse: bad argument");
   HIP_TRY(hipSetDevice(h->device));
-  double *d_in = nullptr, *d_out = nullptr;
-  HIP_TRY(dmalloc(&d_in, (size_t)3 * n));
-  HIP_TRY(dmalloc(&d_out, (size_t)3 * n));
-  HIP_TRY(hipMemcpy(d_in, abc, sizeof(double) * 3 * n, hipMemcpyHostToDevice));
+  void* v = nullptr;
+  int rc = cilqr::scratch_bytes(h, cilqr::SCR_DEBUG, sizeof(double) * 6 * (size_t)n, &v);
+  if (rc) return rc;
+  double *d_in = (double*)v, *d_out = d_in + 3 * (size_t)n;
+  HIP_TRY(hipMemcpyAsync(d_in, abc, sizeof(double) * 3 * n, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(cilqr::launch_blur_ellipse(n, d_in, d_out, h->stream));
+  HIP_TRY(hipMemcpyAsync(out, d_out, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipMemcpy(out, d_out, sizeof(double) * 3 * n, hipMemcpyDeviceToHost));
-  (void)hipFree(d_in); (void)hipFree(d_out);
   return CILQR_OK;
 }
 
@@ -377,52 +380,20 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
 
 }  // extern "C"
 
-namespace cilqr {
-// Host-buffer solve without the final wait: H2D of the inputs, the kernels and D2H of the results, all enqueued on the
-// handle's stream (cilqr_solve_batch = this + hipStreamSynchronize; cilqr_multi_solve_batch enqueues every device first).
-int solve_batch_enqueue(cilqr_handle* h, int B, int N, int M, const double* x0, double* U, const double* poly,
-                        const double* xplan_fl, const double* obs_pose, const double* obs_dim, const double* obs_weight,
-                        double* X_out, double* J_out, int32_t* iters_out, int32_t* status_out, uint32_t flags) {
-  int rc = check_sizes(h, B, N, M);
-  if (rc) return rc;
-  if (B == 0) return CILQR_OK;
-  if (!x0 || !U || !poly || !xplan_fl || !X_out) return fail(CILQR_ERR_ARG, "cilqr_solve_batch: null required pointer");
-  if (M > 0 && (!obs_pose || !obs_dim)) return fail(CILQR_ERR_ARG, "cilqr_solve_batch: M > 0 but obstacle tables are null");
-  HIP_TRY(hipSetDevice(h->device));
-  hipStream_t s = h->stream;
-  const size_t b = B, n = N, m = M;
-  HIP_TRY(hipMemcpyAsync(h->d_x0, x0, b * 4 * sizeof(double), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(h->d_U, U, b * 2 * n * sizeof(double), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(h->d_poly, poly, b * CILQR_POLY_COEFFS * sizeof(double), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(h->d_xplan, xplan_fl, b * 2 * sizeof(double), hipMemcpyHostToDevice, s));
-  if (M > 0) {
-    HIP_TRY(hipMemcpyAsync(h->d_obs_pose, obs_pose, b * m * n * 4 * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(h->d_obs_dim, obs_dim, b * m * n * 2 * sizeof(double), hipMemcpyHostToDevice, s));
-    if (obs_weight) HIP_TRY(hipMemcpyAsync(h->d_obs_w, obs_weight, b * m * sizeof(double), hipMemcpyHostToDevice, s));
-  }
-  rc = cilqr_solve_batch_device(h, s, B, N, M, h->d_x0, h->d_U, h->d_poly, h->d_xplan, h->d_obs_pose, h->d_obs_dim,
-                                (M > 0 && obs_weight) ? h->d_obs_w : nullptr, h->d_X, h->d_J, h->d_iters, h->d_status, flags);
-  if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(U, h->d_U, b * 2 * n * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(X_out, h->d_X, b * 4 * (n + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
-  if (J_out) HIP_TRY(hipMemcpyAsync(J_out, h->d_J, b * sizeof(double), hipMemcpyDeviceToHost, s));
-  if (iters_out) HIP_TRY(hipMemcpyAsync(iters_out, h->d_iters, b * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  if (status_out) HIP_TRY(hipMemcpyAsync(status_out, h->d_status, b * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  return CILQR_OK;
-}
-}  // namespace cilqr
-
 extern "C" {
 
 int cilqr_solve_batch(cilqr_handle* h, int B, int N, int M, const double* x0, double* U, const double* poly,
                       const double* xplan_fl, const double* obs_pose, const double* obs_dim, const double* obs_weight,
                       double* X_out, double* J_out, int32_t* iters_out, int32_t* status_out, uint32_t flags) {
-  int rc = cilqr::solve_batch_enqueue(h, B, N, M, x0, U, poly, xplan_fl, obs_pose, obs_dim, obs_weight, X_out, J_out, iters_out,
-                                      status_out, flags);
+  int rc = check_sizes(h, B, N, M);
   if (rc) return rc;
   if (B == 0) return CILQR_OK;
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  return CILQR_OK;
+  if (!x0 || !U || !poly || !xplan_fl || !X_out) return fail(CILQR_ERR_ARG, "cilqr_solve_batch: null required pointer");
+  if (M > 0 && (!obs_pose || !obs_dim)) return fail(CILQR_ERR_ARG, "cilqr_solve_batch: M > 0 but obstacle tables are null");
+  cilqr::HostBatch q{B, N, M, 0, x0, U, poly, xplan_fl, obs_pose, obs_dim, obs_weight, nullptr, 0.0, X_out, J_out, iters_out, status_out, flags};
+  rc = cilqr::host_solve_enqueue(h, q);
+  if (rc) { h->pending.active = false; return rc; }
+  return cilqr::host_solve_finish(h);
 }
 
 int cilqr_solve_batch_sampled_device(cilqr_handle* h, void* stream, int B, int N, int n_obs, int n_samples, const double* x0,
@@ -468,26 +439,11 @@ int cilqr_solve_batch_sampled(cilqr_handle* h, int B, int N, int n_obs, int n_sa
   if (B == 0) return CILQR_OK;
   if (!x0 || !U || !poly || !xplan_fl || !X_out || !nom_pose || !nom_dim || !sample_offset)
     return fail(CILQR_ERR_ARG, "cilqr_solve_batch_sampled: null required pointer");
-  HIP_TRY(hipSetDevice(h->device));
-  hipStream_t s = h->stream;
-  const size_t b = B, n = N, m = n_obs;
-  HIP_TRY(hipMemcpyAsync(h->d_x0, x0, b * 4 * sizeof(double), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(h->d_U, U, b * 2 * n * sizeof(double), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(h->d_poly, poly, b * CILQR_POLY_COEFFS * sizeof(double), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(h->d_xplan, xplan_fl, b * 2 * sizeof(double), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(h->d_obs_pose, nom_pose, b * m * n * 4 * sizeof(double), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(h->d_obs_dim, nom_dim, b * m * n * 2 * sizeof(double), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(h->d_samp_off, sample_offset, b * m * n_samples * 3 * sizeof(double), hipMemcpyHostToDevice, s));
-  rc = cilqr_solve_batch_sampled_device(h, s, B, N, n_obs, n_samples, h->d_x0, h->d_U, h->d_poly, h->d_xplan, h->d_obs_pose,
-                                        h->d_obs_dim, h->d_samp_off, sample_weight, h->d_X, h->d_J, h->d_iters, h->d_status, flags);
-  if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(U, h->d_U, b * 2 * n * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(X_out, h->d_X, b * 4 * (n + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
-  if (J_out) HIP_TRY(hipMemcpyAsync(J_out, h->d_J, b * sizeof(double), hipMemcpyDeviceToHost, s));
-  if (iters_out) HIP_TRY(hipMemcpyAsync(iters_out, h->d_iters, b * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  if (status_out) HIP_TRY(hipMemcpyAsync(status_out, h->d_status, b * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  return CILQR_OK;
+  cilqr::HostBatch q{B, N, n_obs, n_samples, x0, U, poly, xplan_fl, nom_pose, nom_dim, nullptr, sample_offset, sample_weight, X_out, J_out,
+                     iters_out, status_out, flags};
+  rc = cilqr::host_solve_enqueue(h, q);
+  if (rc) { h->pending.active = false; return rc; }
+  return cilqr::host_solve_finish(h);
 }
 
 int cilqr_argmin_device(cilqr_handle* h, void* stream, int B, const double* J, double* out_pair) {
@@ -531,16 +487,19 @@ int cilqr_blur_costmap(cilqr_handle* h, const float* src, const cilqr_map_geom* 
     HIP_TRY(dmalloc(&h->d_dst, n));
     h->dst_cap = n;
   }
-  int32_t* d_cnt = nullptr;
-  if (count_out) HIP_TRY(dmalloc(&d_cnt, n));
+  void* v_cnt = nullptr;
+  if (count_out) {
+    int rcs = cilqr::scratch_bytes(h, cilqr::SCR_COUNT, n * sizeof(int32_t), &v_cnt);
+    if (rcs) return rcs;
+  }
+  int32_t* d_cnt = (int32_t*)v_cnt;
   hipStream_t s = h->stream;
   HIP_TRY(hipMemcpyAsync(h->d_src, src, n * sizeof(float), hipMemcpyHostToDevice, s));
   int rc = cilqr_blur_costmap_device(h, s, h->d_src, g, index, vtheta, sigma_x, sigma_y, sigma_theta, h->d_dst, d_cnt);
-  if (rc) { if (d_cnt) (void)hipFree(d_cnt); return rc; }
+  if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(out, h->d_dst, n * sizeof(float), hipMemcpyDeviceToHost, s));
   if (count_out) HIP_TRY(hipMemcpyAsync(count_out, d_cnt, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  if (d_cnt) (void)hipFree(d_cnt);
   return CILQR_OK;
 }
 
@@ -567,33 +526,30 @@ int cilqr_local_plan_batch(cilqr_handle* h, int B, int P, const double* path, in
   if (!h || !path || !ego || !poly || !xplan_fl) return fail(CILQR_ERR_ARG, "cilqr_local_plan_batch: null argument");
   if (B < 1 || P < 1 || path_stride < 0) return fail(CILQR_ERR_ARG, "cilqr_local_plan_batch: bad size");
   HIP_TRY(hipSetDevice(h->device));
-  const int W = h->params.num_of_local_wpts;
+  const size_t W = h->params.num_of_local_wpts, b = B;
   const size_t n_path = path_stride ? (size_t)(B - 1) * path_stride + 2 * (size_t)P : 2 * (size_t)P;
-  double *d_path = nullptr, *d_ego = nullptr, *d_poly = nullptr, *d_fl = nullptr, *d_ref = nullptr;
-  int32_t* d_n = nullptr;
-  auto release = [&]() {
-    (void)hipFree(d_path); (void)hipFree(d_ego); (void)hipFree(d_poly); (void)hipFree(d_fl); (void)hipFree(d_ref); (void)hipFree(d_n);
-  };
+  // device scratch owned by the handle (reserved at create for max_batch candidates; the path block grows with the first long path)
+  void *vp = nullptr, *vio = nullptr;
+  int rc = cilqr::scratch_bytes(h, cilqr::SCR_PLAN_PATH, n_path * sizeof(double), &vp);
+  if (rc) return rc;
+  const size_t o_ego = 0, o_poly = o_ego + b * 4, o_fl = o_poly + b * CILQR_POLY_COEFFS, o_ref = o_fl + b * 2, o_n = o_ref + b * 2 * W;
+  rc = cilqr::scratch_bytes(h, cilqr::SCR_PLAN_IO, o_n * sizeof(double) + b * sizeof(int32_t), &vio);
+  if (rc) return rc;
+  double* d_path = (double*)vp;
+  double* io = (double*)vio;
+  int32_t* d_n = (int32_t*)(io + o_n);
   hipStream_t s = h->stream;
-  hipError_t e = dmalloc(&d_path, n_path);
-  if (e == hipSuccess) e = dmalloc(&d_ego, (size_t)B * 4);
-  if (e == hipSuccess) e = dmalloc(&d_poly, (size_t)B * CILQR_POLY_COEFFS);
-  if (e == hipSuccess) e = dmalloc(&d_fl, (size_t)B * 2);
-  if (e == hipSuccess && ref_traj) e = dmalloc(&d_ref, (size_t)B * 2 * W);
-  if (e == hipSuccess && n_out) e = dmalloc(&d_n, (size_t)B);
-  if (e == hipSuccess && ref_traj) e = hipMemsetAsync(d_ref, 0, (size_t)B * 2 * W * sizeof(double), s);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_path, path, n_path * sizeof(double), hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_ego, ego, (size_t)B * 4 * sizeof(double), hipMemcpyHostToDevice, s);
-  if (e != hipSuccess) { release(); HIP_TRY(e); }
-  const int rc = cilqr_local_plan_batch_device(h, s, B, P, d_path, path_stride, d_ego, d_poly, d_fl, d_ref, d_n);
-  if (rc) { release(); return rc; }
-  e = hipMemcpyAsync(poly, d_poly, (size_t)B * CILQR_POLY_COEFFS * sizeof(double), hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(xplan_fl, d_fl, (size_t)B * 2 * sizeof(double), hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess && ref_traj) e = hipMemcpyAsync(ref_traj, d_ref, (size_t)B * 2 * W * sizeof(double), hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess && n_out) e = hipMemcpyAsync(n_out, d_n, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
-  release();
-  HIP_TRY(e);
+  if (ref_traj) HIP_TRY(hipMemsetAsync(io + o_ref, 0, b * 2 * W * sizeof(double), s));
+  HIP_TRY(hipMemcpyAsync(d_path, path, n_path * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(io + o_ego, ego, b * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+  rc = cilqr_local_plan_batch_device(h, s, B, P, d_path, path_stride, io + o_ego, io + o_poly, io + o_fl, ref_traj ? io + o_ref : nullptr,
+                                     n_out ? d_n : nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(poly, io + o_poly, b * CILQR_POLY_COEFFS * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(xplan_fl, io + o_fl, b * 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (ref_traj) HIP_TRY(hipMemcpyAsync(ref_traj, io + o_ref, b * 2 * W * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (n_out) HIP_TRY(hipMemcpyAsync(n_out, d_n, b * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
   return CILQR_OK;
 }
 
@@ -617,25 +573,21 @@ int cilqr_layer_to_occupancy_device(cilqr_handle* h, void* stream, const float* 
 }
 
 namespace {
-// host-buffer conversions: staged through scratch device buffers (convenience / test path, not a per-frame path)
+// host-buffer conversions: staged through the handle's scratch slots
 int convert_host(cilqr_handle* h, const void* in, size_t in_bytes, void* out, size_t out_bytes, bool to_layer, int64_t n, float lo, float hi) {
   HIP_TRY(hipSetDevice(h->device));
   if (n == 0) return CILQR_OK;
   void *d_in = nullptr, *d_out = nullptr;
-  hipStream_t s = h->stream;
-  hipError_t e = hipMalloc(&d_in, in_bytes);
-  if (e == hipSuccess) e = hipMalloc(&d_out, out_bytes);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, s);
-  int rc = CILQR_OK;
-  if (e == hipSuccess)
-    rc = to_layer ? cilqr_occupancy_to_layer_device(h, s, (const int8_t*)d_in, n, (float*)d_out)
-                  : cilqr_layer_to_occupancy_device(h, s, (const float*)d_in, n, lo, hi, (int8_t*)d_out);
-  if (e == hipSuccess && rc == CILQR_OK) e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess && rc == CILQR_OK) e = hipStreamSynchronize(s);
-  (void)hipFree(d_in);
-  (void)hipFree(d_out);
+  int rc = cilqr::scratch_bytes(h, cilqr::SCR_CONV_IN, in_bytes, &d_in);
+  if (rc == CILQR_OK) rc = cilqr::scratch_bytes(h, cilqr::SCR_CONV_OUT, out_bytes, &d_out);
   if (rc) return rc;
-  HIP_TRY(e);
+  hipStream_t s = h->stream;
+  HIP_TRY(hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, s));
+  rc = to_layer ? cilqr_occupancy_to_layer_device(h, s, (const int8_t*)d_in, n, (float*)d_out)
+                : cilqr_layer_to_occupancy_device(h, s, (const float*)d_in, n, lo, hi, (int8_t*)d_out);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
   return CILQR_OK;
 }
 }  // namespace

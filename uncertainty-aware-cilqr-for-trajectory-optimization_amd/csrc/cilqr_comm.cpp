@@ -110,14 +110,14 @@ int cilqr_argmin_global_device(cilqr_handle* h, void* stream, int B, const doubl
 int cilqr_debug_select(cilqr_handle* h, int n, const double* triples, double* out_pair) {
   if (!h || n < 1 || !triples || !out_pair) return fail(CILQR_ERR_ARG, "cilqr_debug_select: bad argument");
   HIP_TRY(hipSetDevice(h->device));
-  double* d = nullptr;
-  HIP_TRY(hipMalloc((void**)&d, sizeof(double) * 3 * (size_t)n));
-  hipError_t e = hipMemcpyAsync(d, triples, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, h->stream);
-  if (e == hipSuccess) e = cilqr::launch_select(d, n, h->d_pair, h->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(out_pair, h->d_pair, sizeof(double) * 2, hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  (void)hipFree(d);
-  HIP_TRY(e);
+  void* v = nullptr;
+  int rc = cilqr::scratch_bytes(h, cilqr::SCR_DEBUG, sizeof(double) * 3 * (size_t)n, &v);
+  if (rc) return rc;
+  double* d = (double*)v;
+  HIP_TRY(hipMemcpyAsync(d, triples, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(cilqr::launch_select(d, n, h->d_pair, h->stream));
+  HIP_TRY(hipMemcpyAsync(out_pair, h->d_pair, sizeof(double) * 2, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   return CILQR_OK;
 }
 
@@ -176,6 +176,9 @@ int cilqr_multi_solve_batch(cilqr_multi* m, int B, int N, int M, const double* x
   const int n = (int)m->h.size();
   if (B < 0 || (long)B > (long)n * m->max_batch_per_device)
     return fail(CILQR_ERR_ARG, "B=%d outside [0,%ld]", B, (long)n * m->max_batch_per_device);
+  if (N < 1 || N > m->h[0]->max_horizon || M < 0 || M > m->h[0]->max_obstacles) return fail(CILQR_ERR_ARG, "N or M outside the sizes given at create");
+  if (B > 0 && (!x0 || !U || !poly || !xplan_fl || !X_out || (M > 0 && (!obs_pose || !obs_dim))))
+    return fail(CILQR_ERR_ARG, "cilqr_multi_solve_batch: null required pointer");
   // contiguous shards by scene: device d owns solves [d*per, min(B, (d+1)*per))
   const int per = (B + n - 1) / n;
   std::vector<int> first(n), cnt(n);
@@ -188,11 +191,12 @@ int cilqr_multi_solve_batch(cilqr_multi* m, int B, int N, int M, const double* x
   for (int d = 0; d < n; ++d) {
     if (cnt[d] == 0) continue;
     const size_t f = first[d];
-    int rc = cilqr::solve_batch_enqueue(m->h[d], cnt[d], N, M, x0 + f * 4, U + f * 2 * sN, poly + f * CILQR_POLY_COEFFS, xplan_fl + f * 2,
-                                        obs_pose ? obs_pose + f * sM * sN * 4 : nullptr, obs_dim ? obs_dim + f * sM * sN * 2 : nullptr,
-                                        obs_weight ? obs_weight + f * sM : nullptr, X_out + f * 4 * (sN + 1), J_out ? J_out + f : nullptr,
-                                        iters_out ? iters_out + f : nullptr, status_out ? status_out + f : nullptr, flags);
-    if (rc) return rc;
+    cilqr::HostBatch q{cnt[d], N, M, 0, x0 + f * 4, U + f * 2 * sN, poly + f * CILQR_POLY_COEFFS, xplan_fl + f * 2,
+                       obs_pose ? obs_pose + f * sM * sN * 4 : nullptr, obs_dim ? obs_dim + f * sM * sN * 2 : nullptr,
+                       obs_weight ? obs_weight + f * sM : nullptr, nullptr, 0.0, X_out + f * 4 * (sN + 1), J_out ? J_out + f : nullptr,
+                       iters_out ? iters_out + f : nullptr, status_out ? status_out + f : nullptr, flags};
+    int rc = cilqr::host_solve_enqueue(m->h[d], q);
+    if (rc) { for (cilqr_handle* hh : m->h) hh->pending.active = false; return rc; }
   }
   // the exchange step: per-device argmin, one grouped all-gather of the 24-byte records, the pick on every device
   for (int d = 0; d < n; ++d) {
@@ -220,7 +224,8 @@ int cilqr_multi_solve_batch(cilqr_multi* m, int B, int N, int M, const double* x
     HIP_TRY(hipMemcpyAsync(pair, h->d_pair, sizeof(pair), hipMemcpyDeviceToHost, h->stream));
   }
   for (int d = 0; d < n; ++d) {
-    HIP_TRY(hipSetDevice(m->h[d]->device));
+    int rc = cilqr::host_solve_finish(m->h[d]);  // waits for the device's stream; unpacks a small shard's staging buffer
+    if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(m->h[d]->stream));
   }
   if (best_J) *best_J = pair[0];

@@ -8,12 +8,37 @@
 
 struct ncclComm;  // RCCL communicator (rccl.h), only named here
 
+struct cilqr_handle;
+
 namespace cilqr {
+// Where a host-buffer call's arrays lie in the handle's device arena and pinned staging buffer (cilqr_host_io.cpp); bytes.
+struct IoLayout {
+  size_t x0, poly, xplan, obs_w, samp_off, obs_pose, obs_dim, U, X, J, iters, status, end;
+};
+IoLayout io_layout(size_t B, size_t N, size_t M, bool weights, size_t n_samples);
+// One host-buffer solve call (M = obstacles, or nominal obstacles of the sampled form when n_samples > 0).
+struct HostBatch {
+  int B, N, M, n_samples;
+  const double *x0;
+  double* U;
+  const double *poly, *xplan_fl, *obs_pose, *obs_dim, *obs_weight, *samp_off;
+  double samp_w;
+  double *X_out, *J_out;
+  int32_t *iters_out, *status_out;
+  uint32_t flags;
+};
+struct PendingOut {
+  bool active, packed;
+  IoLayout L;
+  HostBatch q;
+};
+int host_solve_enqueue(cilqr_handle* h, const HostBatch& q);  // copies in, kernels, copies out: all enqueued on h->stream
+int host_solve_finish(cilqr_handle* h);                       // waits; unpacks the staging buffer of a small call
+enum { SCR_PLAN_PATH, SCR_PLAN_IO, SCR_COUNT, SCR_CONV_IN, SCR_CONV_OUT, SCR_DEBUG, SCR_SLOTS };
+int scratch_bytes(cilqr_handle* h, int slot, size_t bytes, void** out);
+
 extern thread_local std::string g_last_error;
 int fail(int code, const char* fmt, ...);  // records the message for cilqr_last_error() and returns `code`
-int solve_batch_enqueue(cilqr_handle* h, int B, int N, int M, const double* x0, double* U, const double* poly,
-                        const double* xplan_fl, const double* obs_pose, const double* obs_dim, const double* obs_weight,
-                        double* X_out, double* J_out, int32_t* iters_out, int32_t* status_out, uint32_t flags);
 }  // namespace cilqr
 
 #define HIP_TRY(expr)                                                                                      \
@@ -28,9 +53,15 @@ struct cilqr_handle {
   int device;
   int max_batch, max_horizon, max_obstacles;
   hipStream_t stream;
-  // device staging for the host-pointer entry points
-  double *d_x0, *d_U, *d_poly, *d_xplan, *d_obs_pose, *d_obs_dim, *d_obs_w, *d_samp_off, *d_X, *d_J;
-  int32_t *d_iters, *d_status;
+  // host-buffer entry points (cilqr_host_io.cpp): device arena and pinned staging sized at create, the call in flight
+  char* d_arena;
+  size_t arena_cap;
+  char* stage;
+  size_t stage_cap;
+  cilqr::PendingOut pending;
+  double* d_J;  // the costs of the last host-buffer call, inside the arena
+  void* scratch[cilqr::SCR_SLOTS];
+  size_t scratch_cap[cilqr::SCR_SLOTS];
   // workspace
   double* d_obs_tab;
   double* d_ws;      // workspace of the G-lanes-per-solve kernel family
