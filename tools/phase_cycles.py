@@ -17,12 +17,25 @@ X = torch.zeros(B, 4 * (N + 1), dtype=torch.float64, device="cuda"); J = torch.z
 it = torch.zeros(B, dtype=torch.int32, device="cuda"); st = torch.zeros(B, dtype=torch.int32, device="cuda")
 diag = torch.zeros(B, 8, dtype=torch.int64, device="cuda")
 s.set_diag_buffer(diag.data_ptr())
+U0 = U.clone()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for _ in range(2):  # second run timed (same stamped kernel)
+    U.copy_(U0)
+    torch.cuda.synchronize()
+    e0.record()
+    s.solve_batch_device(torch.cuda.current_stream().cuda_stream, B, N, M, x0.data_ptr(), U.data_ptr(), poly.data_ptr(), xpl.data_ptr(), pose.data_ptr() if M else 0,
+                         dim.data_ptr() if M else 0, 0, X.data_ptr(), J.data_ptr(), it.data_ptr(), st.data_ptr())
+    e1.record()
+    torch.cuda.synchronize()
+ms = e0.elapsed_time(e1)
+U.copy_(U0)
 s.solve_batch_device(0, B, N, M, x0.data_ptr(), U.data_ptr(), poly.data_ptr(), xpl.data_ptr(), pose.data_ptr() if M else 0,
                      dim.data_ptr() if M else 0, 0, X.data_ptr(), J.data_ptr(), it.data_ptr(), st.data_ptr())
 torch.cuda.synchronize()
 d = diag.cpu().numpy().astype(np.float64)
 nL, nR = d[:, 5], d[:, 6]
 print("solves", B, "N", N, "M", M)
+print("stamped launch: %.3f ms; longest solve %.0f ticks -> %.2f ticks/ns (shader clock if the counter is the shader clock)" % (ms, d[:, 7].max(), d[:, 7].max() / (ms * 1e6)))
 print("per-solve totals (cycles): mean %.0f  max %.0f" % (d[:, 7].mean(), d[:, 7].max()))
 print("prologue mean %.0f | epilogue mean %.0f" % (d[:, 0].mean(), d[:, 4].mean()))
 print("L per call: %.0f  (calls mean %.1f max %d)" % ((d[:, 1] / nL).mean(), nL.mean(), nL.max()))
