@@ -96,7 +96,8 @@ def bench_warp(args, rank, local_rank, world, dist, dev):
     sg, dg = cilqr_amd.map_geom(*c4["src_geom"]), cilqr_amd.map_geom(*c4["dst_geom"])
     solver = cilqr_amd.Solver(cilqr_amd.default_params(), max_batch=1, max_horizon=1, max_obstacles=0, device=local_rank)
     src = torch.from_numpy(np.ascontiguousarray(c4["src"].T)).to(dev)  # column-major payload
-    dst = torch.zeros(dg.rows * dg.cols, dtype=torch.float32, device=dev)
+    K = max(1, args.frames)
+    dst = torch.zeros(K * dg.rows * dg.cols, dtype=torch.float32, device=dev)
     oob = torch.zeros(1, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     poses = c4["poses"]
@@ -104,10 +105,14 @@ def bench_warp(args, rank, local_rank, world, dist, dev):
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
     def step(k, rec=False):
-        vx, vy, th = poses[(k + 7 * rank) % len(poses)]
         if rec:
             ev0[k].record()
-        solver.warp_costmap_device(stream, src.data_ptr(), sg, dst.data_ptr(), dg, vx, vy, th, 0, 0)  # no out-of-range counter
+        if K == 1:
+            vx, vy, th = poses[(k + 7 * rank) % len(poses)]
+            solver.warp_costmap_device(stream, src.data_ptr(), sg, dst.data_ptr(), dg, vx, vy, th, 0, 0)  # no out-of-range counter
+        else:  # K consecutive frames of the pose stream in one launch
+            idx = (np.arange(K) + K * k + 7 * rank) % len(poses)
+            solver.warp_costmap_batch_device(stream, src.data_ptr(), sg, dst.data_ptr(), dg, poses[idx])
         if rec:
             ev1[k].record()
     for k in range(args.warmup):
@@ -131,17 +136,17 @@ def bench_warp(args, rank, local_rank, world, dist, dev):
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
     if rank == 0:
         cells = dg.rows * dg.cols
-        bytes_launch = 8 * cells  # 4 B read + 4 B write per destination cell
+        bytes_launch = 8 * cells * K  # 4 B read + 4 B write per destination cell
         achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
-        out = {"metric": "costmap warp frames/sec (%dx%d -> %dx%d)" % (sg.rows, sg.cols, dg.rows, dg.cols), "value": args.steps * world / elapsed, "unit": "frames/s",
+        out = {"metric": "costmap warp frames/sec (%dx%d -> %dx%d)" % (sg.rows, sg.cols, dg.rows, dg.cols), "value": K * args.steps * world / elapsed, "unit": "frames/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 payload / f64 index math",
                "data": "synthetic",
                "config": {"workload": ("BASELINE config 4: " if S == 1024 else "size sweep: ") +
-                                      "%dx%d occupancy costmap warp, one frame per step, maps resident in HBM" % (S, S)},
-               "roofline": {"bound": "hbm", "kernel": "warp_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC_BYTES.get(("warp", S)),
-                            "traffic_source": "profiles/r01_wide_rows_summary.md (FETCH_SIZE x2 + WRITE_SIZE)" if S == 1024 else None,
+                                      "%dx%d occupancy costmap warp, %d frame(s) per step and launch, maps resident in HBM" % (S, S, K)},
+               "roofline": {"bound": "hbm", "kernel": "warp_kernel" if K == 1 else "warp_batch_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC_BYTES.get(("warp", S)) if K == 1 else None,
+                            "traffic_source": "profiles/r01_wide_rows_summary.md (FETCH_SIZE x2 + WRITE_SIZE)" if S == 1024 and K == 1 else None,
                             "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch}}
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a rank-0, N=1 measurement
             from oracle import oracle as O
@@ -158,7 +163,7 @@ def bench_warp(args, rank, local_rank, world, dist, dev):
             want = res["w"]
             solver.warp_costmap_device(stream, src.data_ptr(), sg, dst.data_ptr(), dg, *poses[nf - 1], 0, oob.data_ptr())
             torch.cuda.synchronize()
-            got = dst.cpu().numpy().reshape(dg.cols, dg.rows).T
+            got = dst[:dg.rows * dg.cols].cpu().numpy().reshape(dg.cols, dg.rows).T
             out["cpu_baseline"] = {"value": rate, "unit": "frames/s", "cores": threads, "kind": "port", "spread": spread,
                                    "sample": "the first %d frames of the pose stream, OpenMP over cells; one untimed pass, then the "
                                              "median of 3 repetitions of %d passes (>= 2 s each)" % (nf, calls)}
@@ -540,6 +545,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c5", "warp", "blur", "occ", "frame", "plan"],
                     help="c2 (default, the config BASELINE.json's metric is quoted on): B=1024 N=50 M=4; c3: B=4096 N=50, 8x32 "
                          "sampled obstacles; c5: B=8192 per GPU N=80 M=16; warp: config 4, 1024x1024 costmap frames")
+    ap.add_argument("--frames", type=int, default=1, help="warp only: K frames per launch (cilqr_warp_costmap_batch_device)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--materialised", action="store_true",
                     help="c3 only: pass the 256 sampled obstacles as 256 ordinary obstacle tables (cilqr_solve_batch_device) instead "

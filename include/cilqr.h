@@ -363,6 +363,14 @@ int cilqr_warp_costmap_device(cilqr_handle* h, void* stream, const float* src, c
                               float* dst, const cilqr_map_geom* dst_geom,
                               double vx, double vy, double vtheta, const float* bbox,
                               int64_t* n_out_of_range_dev);
+/* K frames in one launch: the same source map warped for K poses (a backlog of odometry ticks, the node's pose-noise candidates,
+ * I/ilqr_uncertainty_node.cpp:82-110) into K destination layers stored back to back (frame k at dst + k*rows*cols).
+ * poses: HOST array [K][3] = (vx, vy, vtheta), read before the call returns; bbox (device, one layer shared by the frames) and
+ * n_out_of_range_dev (device, K int64 counters, zeroed by the call) may be NULL.  1 <= K <= 1024.  Every frame equals what
+ * cilqr_warp_costmap_device gives for its pose, bit for bit. */
+int cilqr_warp_costmap_batch_device(cilqr_handle* h, void* stream, const float* src, const cilqr_map_geom* src_geom, float* dst,
+                                    const cilqr_map_geom* dst_geom, int K, const double* poses, const float* bbox,
+                                    int64_t* n_out_of_range_dev);
 /* --- pose-uncertainty propagation over the vehicle-frame costmap ("blur") ---------- */
 /* thrust_propagateUncertainty (M/src/arbitrary_transformation.cu:8-157, functors M/include/ARBIT.cuh:51-107) together with
  * the copy-through of LocalCostmap::propagateUncertainty (M/src/local_costmap.cpp:483-496): for every cell with linear

@@ -1484,3 +1484,44 @@ def test_cpp_adapter_uncertainty_map(cilqr, oracle, tmp_path):
     assert np.max(np.abs(np.array(out["with_map"]["U"]) - w_on["U"][0])) < TIGHT
     assert np.max(np.abs(np.array(out["cleared"]["U"]) - w_off["U"][0])) < TIGHT
     assert np.max(np.abs(w_on["U"] - w_off["U"])) > 1e-3
+
+
+def test_warp_batch_equals_single_frames(cilqr, oracle):
+    """cilqr_warp_costmap_batch_device (K frames per launch, 16-byte stores) against the single-frame kernel and the oracle,
+    bit for bit: config-4 shape with out-of-range frames and a bbox layer, a small map whose rows are a multiple of 4 but
+    not of the tile, and a map whose rows are not a multiple of 4 (frame-by-frame fallback)."""
+    import torch
+    from cilqr_amd import scenes
+    dev = torch.device("cuda", 0)
+    s = cilqr.Solver(cilqr.default_params(), max_batch=1, max_horizon=1, max_obstacles=0, device=0)
+    stream = torch.cuda.current_stream().cuda_stream
+    try:
+        c4 = scenes.make_c4()
+        cases = [(c4["src"], c4["src_geom"], c4["dst_geom"], np.concatenate([c4["poses"][::43], [[95.0, 0.0, 0.4], [0.0, -70.0, 2.0]]]), True),
+                 (c4["src"][:300, :260], (60.0, 52.0, 0.2, 3.0, -2.0), (10.0, 7.4, 0.1, 5.0, 0.0), c4["poses"][5:9] * [0.3, 0.3, 1.0], False),
+                 (c4["src"][:300, :260], (60.0, 52.0, 0.2, 3.0, -2.0), (15.0, 10.0, 0.1, 7.5, 0.0), c4["poses"][17:20] * [0.3, 0.3, 1.0], True)]
+        for src_h, sgeo, dgeo, poses, with_bbox in cases:
+            src_h = np.asfortranarray(src_h)
+            sg, dg, osg, odg = cilqr.map_geom(*sgeo), cilqr.map_geom(*dgeo), oracle.map_geom(*sgeo), oracle.map_geom(*dgeo)
+            K, cells = len(poses), dg.rows * dg.cols
+            rng = np.random.default_rng(K)
+            bbox_h = None
+            if with_bbox:
+                bbox_h = np.zeros((dg.rows, dg.cols), dtype=np.float32)
+                bbox_h[rng.random(bbox_h.shape) < 0.03] = 100.0
+            d_src = torch.from_numpy(np.ascontiguousarray(src_h.T)).to(dev)
+            d_bbox = torch.from_numpy(np.ascontiguousarray(bbox_h.T)).to(dev) if with_bbox else None
+            d_dst = torch.zeros(K * cells, dtype=torch.float32, device=dev)
+            d_oob = torch.full((K,), -1, dtype=torch.int64, device=dev)
+            s.warp_costmap_batch_device(stream, d_src.data_ptr(), sg, d_dst.data_ptr(), dg, poses, d_bbox.data_ptr() if with_bbox else 0,
+                                        d_oob.data_ptr())
+            torch.cuda.synchronize()
+            got = d_dst.cpu().numpy().reshape(K, dg.cols, dg.rows)
+            for k in range(K):
+                want, woob = oracle.warp(src_h, osg, odg, *poses[k], bbox=bbox_h, threads=16)
+                assert np.array_equal(got[k].T, want, equal_nan=True), (dgeo, k)
+                assert int(d_oob[k].item()) == woob
+                single, soob = s.warp_costmap(src_h, sg, dg, *poses[k], bbox=bbox_h)
+                assert np.array_equal(single, want, equal_nan=True) and soob == woob
+    finally:
+        s.close()

@@ -20,7 +20,7 @@ EXIT_TOLERANCE, EXIT_LAMBDA_MAX, EXIT_MAX_ITER, EXIT_NUMERIC = 0, 1, 2, 3
 ABI_SYMBOLS = (
     "cilqr_params_default", "cilqr_abi_version", "cilqr_device_count", "cilqr_last_error", "cilqr_default_control_seq",
     "cilqr_local_plan", "cilqr_local_plan_batch", "cilqr_local_plan_batch_device", "cilqr_create", "cilqr_destroy", "cilqr_host_alloc", "cilqr_host_free", "cilqr_solve_batch", "cilqr_solve_batch_device", "cilqr_solve_batch_sampled", "cilqr_solve_batch_sampled_device",
-    "cilqr_argmin_device", "cilqr_wait", "cilqr_set_diag_buffer", "cilqr_set_pass_count_buffer", "cilqr_debug_quu_inverse", "cilqr_debug_blur_ellipse", "cilqr_warp_costmap", "cilqr_warp_costmap_device", "cilqr_blur_costmap", "cilqr_blur_costmap_device", "cilqr_map_geom_set",
+    "cilqr_argmin_device", "cilqr_wait", "cilqr_set_diag_buffer", "cilqr_set_pass_count_buffer", "cilqr_debug_quu_inverse", "cilqr_debug_blur_ellipse", "cilqr_warp_costmap", "cilqr_warp_costmap_device", "cilqr_warp_costmap_batch_device", "cilqr_blur_costmap", "cilqr_blur_costmap_device", "cilqr_map_geom_set",
     "cilqr_occupancy_to_layer", "cilqr_occupancy_to_layer_device", "cilqr_layer_to_occupancy", "cilqr_layer_to_occupancy_device",
     "cilqr_costmap_frame_device",
     "cilqr_set_uncertainty_map", "cilqr_set_uncertainty_map_device", "cilqr_clear_uncertainty_map", "cilqr_debug_uncertainty_cost",
@@ -371,6 +371,12 @@ class Solver:
                                                C.byref(dst_geom), C.c_double(vx), C.c_double(vy), C.c_double(vtheta),
                                                _vp(bbox), _vp(n_oob)))
 
+
+    def warp_costmap_batch_device(self, stream, src, src_geom, dst, dst_geom, poses, bbox=0, n_oob=0):
+        """poses: (K, 3) host array of (vx, vy, vtheta); dst: device address of K destination layers back to back."""
+        poses = _np64(poses).reshape(-1, 3)
+        _check(lib().cilqr_warp_costmap_batch_device(self._h, _vp(stream), _vp(src), C.byref(src_geom), _vp(dst), C.byref(dst_geom),
+                                                     int(poses.shape[0]), _p(poses), _vp(bbox), _vp(n_oob)))
 
     def blur_costmap(self, src, geom, vtheta, sigma_x, sigma_y, sigma_theta, index=0):
         """src: (rows, cols) float32.  Returns (out F-ordered float32, counts (rows*cols,) int32)."""

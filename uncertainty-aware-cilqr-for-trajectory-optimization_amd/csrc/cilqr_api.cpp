@@ -168,6 +168,7 @@ int cilqr_create(const cilqr_params* p, int max_batch, int max_horizon, int max_
   if (err == hipSuccess) err = dmalloc(&h->d_gather, (size_t)3);
   h->comm_ranks = 1;
   if (err == hipSuccess) err = dmalloc(&h->d_oob, (size_t)1);
+  if (err == hipSuccess) err = dmalloc(&h->d_poses, (size_t)8 * 1024 * 4);
   if (err == hipSuccess) err = dmalloc(&h->d_occ_steps, (size_t)8 * 128);
   if (err == hipSuccess) {  // scratch of cilqr_local_plan_batch for max_batch candidates and a 1024-waypoint path
     void* unused = nullptr;
@@ -193,7 +194,7 @@ int cilqr_destroy(cilqr_handle* h) {
   if (h->stage) (void)hipHostFree(h->stage);
   for (void* p : h->scratch)
     if (p) (void)hipFree(p);
-  void* ptrs[] = {h->d_unc_layer, h->d_triple, h->d_gather, h->d_arena, h->d_obs_tab, h->d_ws, h->d_redo, h->d_pair, h->d_src, h->d_dst, h->d_bbox, h->d_oob, h->d_occ_steps};
+  void* ptrs[] = {h->d_poses, h->d_unc_layer, h->d_triple, h->d_gather, h->d_arena, h->d_obs_tab, h->d_ws, h->d_redo, h->d_pair, h->d_src, h->d_dst, h->d_bbox, h->d_oob, h->d_occ_steps};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -654,6 +655,44 @@ int cilqr_warp_costmap_device(cilqr_handle* h, void* stream, const float* src, c
   a.cos_t = cos(vtheta);
   if (n_oob_dev) HIP_TRY(hipMemsetAsync(n_oob_dev, 0, sizeof(int64_t), s));
   HIP_TRY(cilqr::launch_warp(a, s));
+  return CILQR_OK;
+}
+
+int cilqr_warp_costmap_batch_device(cilqr_handle* h, void* stream, const float* src, const cilqr_map_geom* sg, float* dst,
+                                    const cilqr_map_geom* dg, int K, const double* poses, const float* bbox, int64_t* n_oob_dev) {
+  if (!h || !src || !sg || !dst || !dg || !poses) return fail(CILQR_ERR_ARG, "cilqr_warp_costmap_batch: null argument");
+  if (K < 1 || K > 1024) return fail(CILQR_ERR_ARG, "cilqr_warp_costmap_batch: K=%d outside [1,1024]", K);
+  if (sg->rows < 1 || sg->cols < 1 || dg->rows < 1 || dg->cols < 1 || !(sg->res > 0.0) || !(dg->res > 0.0))
+    return fail(CILQR_ERR_ARG, "cilqr_warp_costmap_batch: bad geometry");
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipSetDevice(h->device));
+  if (dg->rows % 4 != 0) {  // the 16-byte-store kernel needs rows in fours: frame by frame with the single-frame kernel
+    const size_t cells = (size_t)dg->rows * dg->cols;
+    for (int k = 0; k < K; ++k) {
+      int rc = cilqr_warp_costmap_device(h, stream, src, sg, dst + (size_t)k * cells, dg, poses[3 * k], poses[3 * k + 1], poses[3 * k + 2], bbox,
+                                         n_oob_dev ? n_oob_dev + k : nullptr);
+      if (rc) return rc;
+    }
+    return CILQR_OK;
+  }
+  double table[1024 * 4];
+  for (int k = 0; k < K; ++k) {
+    table[4 * k] = poses[3 * k];
+    table[4 * k + 1] = poses[3 * k + 1];
+    table[4 * k + 2] = sin(poses[3 * k + 2]);  // host libm, as the reference (M/src/local_costmap.cpp:201-202)
+    table[4 * k + 3] = cos(poses[3 * k + 2]);
+  }
+  // eight device slots in rotation keep the tables of calls still in flight (on other streams) apart; the copy itself is
+  // staged by the runtime before this call returns (pageable source)
+  double* d_table = h->d_poses + (size_t)1024 * 4 * (h->pose_slot++ & 7);
+  HIP_TRY(hipMemcpyAsync(d_table, table, sizeof(double) * 4 * K, hipMemcpyHostToDevice, s));
+  if (n_oob_dev) HIP_TRY(hipMemsetAsync(n_oob_dev, 0, sizeof(int64_t) * K, s));
+  cilqr::WarpBatchArgs a;
+  a.src = src; a.dst = dst; a.bbox = bbox;
+  a.n_oob = (unsigned long long*)n_oob_dev;
+  a.poses = d_table;
+  a.sg = *sg; a.dg = *dg;
+  HIP_TRY(cilqr::launch_warp_batch(a, K, s));
   return CILQR_OK;
 }
 

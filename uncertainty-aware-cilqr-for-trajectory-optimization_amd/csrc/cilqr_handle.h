@@ -72,6 +72,8 @@ struct cilqr_handle {
   float *d_src, *d_dst, *d_bbox;
   size_t src_cap, dst_cap, bbox_cap;
   unsigned long long* d_oob;
+  double* d_poses;       // 8 slots x 1024 poses x 4 doubles: pose tables of cilqr_warp_costmap_batch_device calls in flight
+  unsigned pose_slot;
   float* d_occ_steps;  // 8 x 128 floats: step tables of the layer -> occupancy conversion (rebuilt per call on the call's stream)
   unsigned occ_slot;
   unsigned long long* diag;  // caller-owned device buffer or null

@@ -105,6 +105,17 @@ struct WarpArgs {
   double vx, vy, sin_t, cos_t;
 };
 hipError_t launch_warp(const WarpArgs& a, hipStream_t stream);
+// K frames per launch (dst rows must be a multiple of 4): poses [K][4] = (vx, vy, sin theta, cos theta) on the device,
+// destination frames back to back, n_oob [K] or null.
+struct WarpBatchArgs {
+  const float* src;
+  float* dst;
+  const float* bbox;          // may be null (one layer, shared by the frames)
+  unsigned long long* n_oob;  // may be null
+  const double* poses;
+  cilqr_map_geom sg, dg;
+};
+hipError_t launch_warp_batch(const WarpBatchArgs& a, int K, hipStream_t stream);
 
 struct BlurArgs {
   const float* src;

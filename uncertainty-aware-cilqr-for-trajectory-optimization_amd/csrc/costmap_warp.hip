@@ -90,7 +90,90 @@ __global__ __launch_bounds__(NTHREADS) void warp_kernel(WarpArgs a, int tiles_i,
   }
 }
 
+// ---- K frames per launch, four consecutive rows per lane -------------------------------------------------------------------------
+// One 1024² frame is 8 MiB of traffic: ≈1 µs at HBM speed against ≈5 µs of launch and ramp — a single frame cannot be
+// bandwidth-bound.  A pose stream (the node's pose-noise candidates, a backlog of odometry ticks at 30 Hz) is warped K frames per
+// launch instead: blockIdx.y = frame, pose (vx, vy, sin, cos) from a device table, destination frames back to back.  A lane owns
+// four consecutive rows i of one column: ONE 16-byte store (and one 16-byte bbox load) per lane and column, a whole KiB per
+// wavefront instruction, the four source cells gathered separately (they are neighbours in the source: same or adjacent
+// lines).  The per-cell index arithmetic is the single-frame kernel's, bit for bit.
+constexpr int VT_I = 256;  // rows per tile = 64 lanes x 4
+constexpr int VT_J = 8;    // columns per tile: wave w handles j = w, w + 4
+
+__global__ __launch_bounds__(NTHREADS) void warp_batch_kernel(WarpBatchArgs a, int tiles_i) {
+#pragma clang fp contract(off)
+  const int frame = blockIdx.y;
+  const double* pose = a.poses + 4 * (size_t)frame;
+  const double vx = pose[0], vy = pose[1], sin_t = pose[2], cos_t = pose[3];
+  const int ti = blockIdx.x % tiles_i, tj = blockIdx.x / tiles_i;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i0 = ti * VT_I + 4 * lane;
+  const int drows = a.dg.rows, dcols = a.dg.cols;
+  const size_t frame_cells = (size_t)drows * dcols;
+  float* dst = a.dst + frame * frame_cells;
+  const double off_dx = 0.5 * a.dg.len_x - 0.5 * a.dg.res, off_dy = 0.5 * a.dg.len_y - 0.5 * a.dg.res;
+  const double off_sx = 0.5 * a.sg.len_x, off_sy = 0.5 * a.sg.len_y;
+  const double rres = 1.0 / a.sg.res;
+  double cxc[4], cxs[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double Cx = (a.dg.pos_x + off_dx) + a.dg.res * (double)(-(i0 + k));
+    cxc[k] = Cx * cos_t;
+    cxs[k] = Cx * sin_t;
+  }
+  unsigned long long oob = 0;
+  const bool in_i = i0 < drows;  // drows is a multiple of 4 on this path: a lane's four rows are all inside or all outside
+#pragma unroll
+  for (int jj = 0; jj < VT_J / 4; ++jj) {
+    const int j = tj * VT_J + wave + 4 * jj;
+    if (j >= dcols || !in_i) break;
+    const double Cy = (a.dg.pos_y + off_dy) + a.dg.res * (double)(-j);
+    const double cys = Cy * sin_t, cyc = Cy * cos_t;
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double x_og = (cxc[k] - cys) + vx;
+      const double y_og = (cxs[k] + cyc) + vy;
+      const double nx = neg_quotient_for_trunc((x_og - off_sx) - a.sg.pos_x, a.sg.res, rres);
+      const double ny = neg_quotient_for_trunc((y_og - off_sy) - a.sg.pos_y, a.sg.res, rres);
+      const double tx = -1.0 * ((x_og - a.sg.pos_x) - off_sx);
+      const double ty = -1.0 * ((y_og - a.sg.pos_y) - off_sy);
+      const bool fin = (nx > -2e9 && nx < 2e9 && ny > -2e9 && ny < 2e9);
+      const int si = fin ? (int)nx : -1, sj = fin ? (int)ny : -1;
+      const bool ok = (tx >= 0.0 && ty >= 0.0 && tx < a.sg.len_x && ty < a.sg.len_y) &&
+                      (si >= 0 && sj >= 0 && si < a.sg.rows && sj < a.sg.cols);
+      if (ok) {
+        v[k] = a.src[(size_t)sj * a.sg.rows + si];
+      } else {
+        v[k] = __builtin_nanf("");
+        ++oob;
+      }
+    }
+    const size_t lin = (size_t)j * drows + i0;
+    if (a.bbox) {
+      const float4 bb = *reinterpret_cast<const float4*>(a.bbox + lin);
+      if (bb.x > 90.0f) v[0] = bb.x;
+      if (bb.y > 90.0f) v[1] = bb.y;
+      if (bb.z > 90.0f) v[2] = bb.z;
+      if (bb.w > 90.0f) v[3] = bb.w;
+    }
+    *reinterpret_cast<float4*>(dst + lin) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  if (a.n_oob) {
+    for (int o = 32; o > 0; o >>= 1) oob += __shfl_xor(oob, o, 64);
+    if (lane == 0 && oob) atomicAdd(a.n_oob + frame, oob);
+  }
+}
+
 }  // namespace
+
+hipError_t launch_warp_batch(const WarpBatchArgs& a, int K, hipStream_t stream) {
+  if (K <= 0) return hipSuccess;
+  if (a.dg.rows % 4 != 0) return hipErrorInvalidValue;  // the caller falls back to per-frame launches
+  const int tiles_i = (a.dg.rows + VT_I - 1) / VT_I, tiles_j = (a.dg.cols + VT_J - 1) / VT_J;
+  hipLaunchKernelGGL(warp_batch_kernel, dim3(tiles_i * tiles_j, K), dim3(NTHREADS), 0, stream, a, tiles_i);
+  return hipGetLastError();
+}
 
 hipError_t launch_warp(const WarpArgs& a, hipStream_t stream) {
   const int tiles_i = (a.dg.rows + TILE_I - 1) / TILE_I, tiles_j = (a.dg.cols + TILE_J - 1) / TILE_J;
