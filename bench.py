@@ -31,9 +31,9 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (cannot be collected inside this process): FETCH_SIZE
 # doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950, plus WRITE_SIZE.  Keyed by (workload, batch).
-PMC_TRAFFIC_BYTES = {("c2", 1024): 2 * 5657.96e3 + 2560e3,      # profiles/r01_final_solver_summary.md
-                     ("c3", 4096): 2 * 213649e3 + 112780e3,     # compact sampled form (materialised: ≈ 23 GB)
-                     ("c5", 8192): 2 * 2.51843e9 + 3.38345e9,   # the global workspace of the grouped family
+PMC_TRAFFIC_BYTES = {("c2", 1024): 2 * 5658.55e3 + 2592e3,      # profiles/r02_solver_summary.md
+                     ("c3", 4096): 2 * 160094e3 + 112952e3,     # compact sampled form (materialised: ≈ 23 GB)
+                     ("c5", 8192): 2 * 1.70467e9 + 1.83323e9,   # the global workspace of the grouped family (r01: 8.42 GB)
                      # profiles/r01_wide_rows_summary.md (KB per dispatch): the 1024^2 destination reads a 512^2 patch of the source
                      ("warp", 1024): 2 * 598.438e3 + 4096e3,
                      ("occ", 8192): 2 * 131103e3 + 65536e3}
@@ -692,10 +692,10 @@ def main():
             "config": {"workload": wl + ", inputs resident in HBM, + min-cost selection",
                        "batch_per_gpu": B, "horizon": N, "obstacles": M, "mean_reference_iterations": mean_iters,
                        "parallelism": "scene-sharded x%d, one ncclAllGather of 24 B per rank behind cilqr_argmin_global_device" % world},
-            "roofline": {"bound": "hbm", "kernel": "cilqr_solve_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "cilqr_solve_kernel" if (B <= 1280 or M > 32) else "cilqr_solve_groups_fast", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if (args.workload == "c3" and args.materialised) else PMC_TRAFFIC_BYTES.get((args.workload, B)),
-                         "traffic_source": "profiles/r01_final_solver_summary.md (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+                         "traffic_source": "profiles/r02_solver_summary.md (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
                          if (args.workload, B) in PMC_TRAFFIC_BYTES and not (args.workload == "c3" and args.materialised) else None,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch,
                          "note": "latency/fp64-VALU-bound path: HBM fraction is tiny by design (LDS-resident solve); see fp64_valu"},

@@ -16,7 +16,7 @@ for w in c2 c3 c5; do
 done
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/c2_pmc_SQ -o c2 -- python3 $ROOT/bench.py --workload c2 --steps 4 --warmup 1 --no-cpu-baseline > $OUT/c2_pmc_SQ.log 2>&1
 cd $ROOT
-python3 tools/prof_summary.py "${PROF_TITLE:-r02 — solver configurations 2, 3 (compact sampled obstacles), 5}: `bench.py --workload cN --no-cpu-baseline`" \
+python3 tools/prof_summary.py "${PROF_TITLE:-r02 — solver configurations 2, 3 (compact sampled obstacles), 5: bench.py --workload cN --no-cpu-baseline}" \
   $OUT/c2_stats $OUT/c3_stats $OUT/c5_stats $OUT/c2_pmc_FETCH_SIZE $OUT/c2_pmc_WRITE_SIZE $OUT/c3_pmc_FETCH_SIZE $OUT/c3_pmc_WRITE_SIZE \
   $OUT/c5_pmc_FETCH_SIZE $OUT/c5_pmc_WRITE_SIZE $OUT/c2_pmc_SQ > $ROOT/gpurun_out/prof_solver_summary.md
 du -sh $OUT
