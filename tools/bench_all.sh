@@ -8,7 +8,9 @@ run c2
 run c3 --workload c3 --steps 10 --warmup 2
 run c3_materialised --workload c3 --materialised --steps 10 --warmup 2 --no-cpu-baseline
 run c5 --workload c5 --steps 10 --warmup 2
+run c1 --workload c1
 run warp --workload warp --steps 100 --warmup 10
+run warp_k16 --workload warp --frames 16 --steps 50 --warmup 5 --no-cpu-baseline
 run blur --workload blur
 run occ --workload occ --steps 30 --warmup 3
 run frame --workload frame
