@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libcilqr_hip.so")
+LIB_PATH = os.environ.get("CILQR_LIB") or os.path.join(PKG_ROOT, "lib", "libcilqr_hip.so")  # CILQR_LIB: A/B builds when tuning
 
 NX, NU, POLY = 4, 2, 6
 FLAG_FAITHFUL_ITERS = 1

@@ -323,70 +323,68 @@ __device__ __forceinline__ ObsEntry make_obs_entry(const KParams& kp, const doub
 // occupancy as GridMap::atPositionLinearInterpolated, G/grid_map_core/src/GridMap.cpp:770-837 → exponential barrier in the form
 // of Obstacle::barrier_function, I/Obstacle.cpp:21-32; derivatives w.r.t. (x, y) only).  PARITY UNPINNED: the tests check it
 // against an independent plain-C statement of the same definition.
-struct UncProbe {  // one solve's view of the map
-  const float* layer;
-  int rows, cols, nl, nw;
-  double x_first, y_first, inv_res, px, py, cp, sp, la0, la_step, wb0, wb_step, q1, q2, scale;
-  // (x, y): state position; (ct, st): cos / sin of its heading.  Adds scale·(vx, mx) to the gradient / Hessian sums and returns
-  // the mean barrier value (diagnostics only: get_J does not contain it, I/Constraints.cpp:553-557).
-  __device__ __forceinline__ double operator()(double x, double y, double ct, double st, double& lx0, double& lx1, double& h00,
-                                               double& h01, double& h11) const {
-#pragma clang fp contract(off)  // probe positions and cell indices as the plain-C statement forms them
-    double sx = 0.0, gx = 0.0, gy = 0.0, hxx = 0.0, hxy = 0.0, hyy = 0.0;
-    for (int k = 0; k < nl; ++k) {
-      const double a = la0 + (double)k * la_step;
-      for (int l = 0; l < nw; ++l) {
-        const double b = wb0 + (double)l * wb_step;
-        const double Px = x + (a * ct - b * st), Py = y + (a * st + b * ct);
-        const double dx = Px - px, dy = Py - py;
-        const double qx = cp * dx + sp * dy, qy = cp * dy - sp * dx;
-        const double fi = (x_first - qx) * inv_res, fj = (y_first - qy) * inv_res;
-        if (!(fi >= 0.0) || !(fj >= 0.0) || !(fi < (double)(rows - 1)) || !(fj < (double)(cols - 1))) continue;
-        const int i0 = (int)fi, j0 = (int)fj;
-        const double ti = fi - (double)i0, tj = fj - (double)j0;
-        const float* c0 = layer + (size_t)j0 * rows + i0;
-        const double f00 = c0[0], f10 = c0[1], f01 = c0[rows], f11 = c0[rows + 1];
-        const double big = 1.0e300;  // finite test without library calls (NaN fails every comparison)
-        if (!(fabs(f00) < big && fabs(f10) < big && fabs(f01) < big && fabs(f11) < big)) continue;
-        const double a0 = f00 + ti * (f10 - f00), a1 = f01 + ti * (f11 - f01);
-        const double o = a0 + tj * (a1 - a0);
-        const double di = (f10 - f00) + tj * ((f11 - f01) - (f10 - f00));
-        const double dj = a1 - a0;
-        const double cqx = (-di * inv_res) * 0.01, cqy = (-dj * inv_res) * 0.01;
-        const double cX = cp * cqx - sp * cqy, cY = sp * cqx + cp * cqy;
-        const double e = q1 * exp_fast(q2 * (o * 0.01 - 1.0));
-        const double sv = q2 * e, sm = q2 * q2 * e;
-        sx += e;
-        gx += sv * cX;
-        gy += sv * cY;
-        hxx += (sm * cX) * cX;
-        hxy += (sm * cX) * cY;
-        hyy += (sm * cY) * cY;
-      }
-    }
-    lx0 += gx * scale;
-    lx1 += gy * scale;
-    h00 += hxx * scale;
-    h01 += hxy * scale;
-    h11 += hyy * scale;
-    return sx / (double)(nl * nw);
-  }
+struct UncPose {  // pose of solve b's map frame in the planning frame: position, cos and sin of its heading
+  double px, py, cp, sp;
 };
-// Solve b's probe from the kernel-argument block (read through phase_args() inside phase L, so its ~20 scalars live there only).
-__device__ __forceinline__ UncProbe make_unc_probe(const UncArgs& u, int b) {
-  UncProbe q;
-  q.layer = u.layer + (size_t)b * (size_t)u.stride;
-  q.rows = u.rows; q.cols = u.cols; q.nl = u.nl; q.nw = u.nw;
-  q.x_first = u.x_first; q.y_first = u.y_first; q.inv_res = u.inv_res;
-  q.px = u.px; q.py = u.py; q.cp = u.cp; q.sp = u.sp;
+// Formed once per solve, in the prologue (a per-solve pose costs a sincos).  `u` is the block in the kernel-argument segment.
+__device__ __forceinline__ UncPose unc_pose(const UncArgs& u, int b) {
+  UncPose q{u.px, u.py, u.cp, u.sp};
   if (u.poses) {
     const double* po = u.poses + 3 * (size_t)b;
     q.px = po[0]; q.py = po[1];
     sincos(po[2], &q.sp, &q.cp);
   }
-  q.la0 = u.la0; q.la_step = u.la_step; q.wb0 = u.wb0; q.wb_step = u.wb_step;
-  q.q1 = u.q1; q.q2 = u.q2; q.scale = u.scale;
   return q;
+}
+// (x, y): state position; (ct, st): cos / sin of its heading.  Adds w_uncertainty·(vx, mx) to the gradient / Hessian sums and
+// returns the mean barrier value (diagnostics only: get_J does not contain it, I/Constraints.cpp:553-557).  The map's constants
+// are read from `u` (kernel-argument segment: scalar loads) where they are used — nothing of the map is carried in registers
+// or on a stack between calls.
+__device__ __forceinline__ double unc_cost_add(const UncArgs& u, const UncPose& po, int b, double x, double y, double ct, double st,
+                                               double& lx0, double& lx1, double& h00, double& h01, double& h11) {
+#pragma clang fp contract(off)  // probe positions and cell indices as the plain-C statement forms them
+  const float* layer = u.layer + (size_t)b * (size_t)u.stride;
+  const int rows = u.rows, cols = u.cols, nl = u.nl, nw = u.nw;
+  const double x_first = u.x_first, y_first = u.y_first, inv_res = u.inv_res;
+  const double la0 = u.la0, la_step = u.la_step, wb0 = u.wb0, wb_step = u.wb_step, q1 = u.q1, q2 = u.q2, scale = u.scale;
+  double sx = 0.0, gx = 0.0, gy = 0.0, hxx = 0.0, hxy = 0.0, hyy = 0.0;
+  for (int k = 0; k < nl; ++k) {
+    const double a = la0 + (double)k * la_step;
+    for (int l = 0; l < nw; ++l) {
+      const double bb = wb0 + (double)l * wb_step;
+      const double Px = x + (a * ct - bb * st), Py = y + (a * st + bb * ct);
+      const double dx = Px - po.px, dy = Py - po.py;
+      const double qx = po.cp * dx + po.sp * dy, qy = po.cp * dy - po.sp * dx;
+      const double fi = (x_first - qx) * inv_res, fj = (y_first - qy) * inv_res;
+      if (!(fi >= 0.0) || !(fj >= 0.0) || !(fi < (double)(rows - 1)) || !(fj < (double)(cols - 1))) continue;
+      const int i0 = (int)fi, j0 = (int)fj;
+      const double ti = fi - (double)i0, tj = fj - (double)j0;
+      const float* c0 = layer + (size_t)j0 * rows + i0;
+      const double f00 = c0[0], f10 = c0[1], f01 = c0[rows], f11 = c0[rows + 1];
+      const double big = 1.0e300;  // finite test without library calls (NaN fails every comparison)
+      if (!(fabs(f00) < big && fabs(f10) < big && fabs(f01) < big && fabs(f11) < big)) continue;
+      const double a0 = f00 + ti * (f10 - f00), a1 = f01 + ti * (f11 - f01);
+      const double o = a0 + tj * (a1 - a0);
+      const double di = (f10 - f00) + tj * ((f11 - f01) - (f10 - f00));
+      const double dj = a1 - a0;
+      const double cqx = (-di * inv_res) * 0.01, cqy = (-dj * inv_res) * 0.01;
+      const double cX = po.cp * cqx - po.sp * cqy, cY = po.sp * cqx + po.cp * cqy;
+      const double e = q1 * exp_fast(q2 * (o * 0.01 - 1.0));
+      const double sv = q2 * e, sm = q2 * q2 * e;
+      sx += e;
+      gx += sv * cX;
+      gy += sv * cY;
+      hxx += (sm * cX) * cX;
+      hxy += (sm * cX) * cY;
+      hyy += (sm * cY) * cY;
+    }
+  }
+  lx0 += gx * scale;
+  lx1 += gy * scale;
+  h00 += hxx * scale;
+  h01 += hxy * scale;
+  h11 += hyy * scale;
+  return sx / (double)(nl * nw);
 }
 
 // One per-step linearisation record.
@@ -404,11 +402,13 @@ struct Rec {
 // O(10) factors to any sum — it is skipped after the 22 instructions that establish this, before its two exponentials.  The
 // gradient and Hessian sums it would have been added to are O(1e-3 … 1e3): the omission is below 1e-26 absolute, i.e. far
 // below one ulp of anything it feeds (measured: max|ΔU| against the oracle unchanged).  NaN exponents never vote to skip.
-// `unc`: null, or the solve's uncertainty-map probe (its term is added after the obstacles', I/Constraints.cpp:188-201).
+// The uncertainty-map term (I/Constraints.cpp:188-201) is NOT added here: the kernels add it to the stored record in a loop of
+// its own (unc_cost_add — after the obstacle terms, i.e. in the reference's order of summation), which keeps its registers out of
+// the obstacle loop's allocation (inlined here it cost the table-streaming configuration a third of its speed).
 template <bool CULL = false, typename ObsAt>
 __device__ __forceinline__ double lin_step(const KParams& kp, double px, double py, double v, double ct, double st, double u0,
                                            double u1, double vn, double cn, double sn, double cx, double cy, int M, ObsAt obs,
-                                           Rec& r, const UncProbe* unc = nullptr) {
+                                           Rec& r) {
   const double dt = kp.dt;
   // --- tracking cost (I/Constraints.cpp:163-174)
   const double dx = px - cx, dy = py - cy, dv = v - kp.desired_speed;
@@ -476,9 +476,6 @@ __device__ __forceinline__ double lin_step(const KParams& kp, double px, double 
     if (vb) add_entry(eb, wb);
   }
   if (m < M && va) add_entry(ea, wa);
-
-  // --- uncertainty map (I/Constraints.cpp:188-201)
-  if (unc) (*unc)(px, py, ct, st, lx0, lx1, h00, h01, h11);
 
   // --- control cost (I/Constraints.cpp:110-131)
   const double e1 = exp_fast(kp.q2_acc * (u0 - kp.acc_max));

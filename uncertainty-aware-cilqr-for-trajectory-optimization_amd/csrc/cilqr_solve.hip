@@ -165,7 +165,7 @@ struct SampledSource {
 template <typename Source>
 __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int lane, const double* samp, int S,
                                             const SampleGrid& grid, const double* X, const double* U, double* rec,
-                                            const Source& src, const UncProbe* unc) {
+                                            const Source& src, const UncArgs* unc, UncPose upose, int ub) {
   double Jpart = 0.0;
   for (int t = lane; t < N; t += WAVE) {
     const double* xr = X + t * XR;
@@ -174,11 +174,20 @@ __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int
     const int cs = closest_sample(S, grid, px, py, LdsSamples{samp});
     Rec c;
     Jpart += lin_step<true>(kp, px, py, xr[2], xr[4], xr[5], U[2 * t], U[2 * t + 1], xn[2], xn[4], xn[5], samp[2 * cs],
-                      samp[2 * cs + 1], M, src.at(t), c, unc);
+                      samp[2 * cs + 1], M, src.at(t), c);
     double* r = rec + t * REC;
     r[0] = c.lx0; r[1] = c.lx1; r[2] = c.lx2; r[3] = c.l00; r[4] = c.l01; r[5] = c.l11;
     r[6] = c.lu0; r[7] = c.lu1; r[8] = c.luu0; r[9] = c.luu1;
     r[10] = c.al; r[11] = c.be; r[12] = c.ga; r[13] = c.de; r[14] = c.p; r[15] = c.q;
+  }
+  if (unc) {  // uniform: a map is set — its term joins l_x, l_xx after the obstacles' (I/Constraints.cpp:188-201)
+    for (int t = lane; t < N; t += WAVE) {
+      const double* xr = X + t * XR;
+      double* r = rec + t * REC;
+      double lx0 = r[0], lx1 = r[1], h00 = r[3], h01 = r[4], h11 = r[5];
+      unc_cost_add(*unc, upose, ub, xr[0], xr[1], xr[4], xr[5], lx0, lx1, h00, h01, h11);
+      r[0] = lx0; r[1] = lx1; r[3] = h00; r[4] = h01; r[5] = h11;
+    }
   }
   return Jpart;
 }
@@ -329,11 +338,14 @@ __device__ __forceinline__ bool rollout_fast(const KParams& kp, int N, const dou
 // total}.  A separate instantiation so that the production kernel carries no stamps.
 // TAB: where a step's obstacle entries come from — 0: the table in the global workspace; 1: the table in LDS (chosen by the
 // launcher when it fits beside the rest at the wanted residency); 2: sampled obstacles, derived on the fly (SampledObstacles).
+// UNC: an uncertainty map is set (cilqr_set_uncertainty_map*).  A separate instantiation because the mere presence of the map
+// term's code — even behind a branch never taken — cost config 2 1.2 % through register allocation (A/B on one box: 0.7463 vs
+// 0.7556 ms): without a map the kernel that runs contains none of it.
 // GENERAL: false = the production kernel: branch-free fast passes.  A solve that meets anything the fast passes do not
 // cover (Q_uu not positive semi-definite or not finite; a heading beyond the in-loop sincos range) stops WITHOUT touching
 // its outputs and sets a.redo[b]; the GENERAL = true kernel, launched right behind on the same stream, redoes exactly
 // those solves from their untouched inputs with the branching passes and returns at once for all others.
-template <bool DIAG, int TAB, bool GENERAL>
+template <bool DIAG, int TAB, bool GENERAL, bool UNC>
 __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   unsigned long long tk0 = 0, tk = 0, c_pro = 0, c_L = 0, c_R = 0, c_F = 0, n_L = 0, n_R = 0;
   if (DIAG) tk0 = tk = __builtin_readcyclecounter();
@@ -349,7 +361,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   const KParams kp = a.kp;
   const int N = a.N, M = a.M, S = kp.n_samples;
   const int n_entries = TAB == 2 ? M * a.n_samples : M;  // obstacle entries per step
-  const bool has_unc = a.unc.layer != nullptr;
+  const bool has_unc = UNC;
   if (b >= a.B) return;
   if (GENERAL && a.redo[b] == 0) return;
 
@@ -425,6 +437,8 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
     grid.dmax = readfirstlane_f64(wave_max(m));
   }
 
+  UncPose upose{0, 0, 1, 0};
+  if (has_unc) upose = unc_pose(a.unc, b);
   bool handover = false;  // fast kernel only: this solve needs the GENERAL kernel
   if (GENERAL) {          // nominal rollout, I/iLQR.cpp:51-62
     const double* x0 = a.x0 + (size_t)b * 4;
@@ -459,15 +473,10 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
     {
       double part;
       const KParams kpl = phase_params();  // phase-local read of the parameter block (cilqr_device.hpp)
-      UncProbe probe;
-      const UncProbe* unc = nullptr;
-      if (has_unc) {  // uniform: a map is set (cilqr_set_uncertainty_map*)
-        probe = make_unc_probe(phase_args().unc, b);
-        unc = &probe;
-      }
+      const UncArgs* unc = has_unc ? &phase_args().unc : nullptr;  // uniform: a map is set (cilqr_set_uncertainty_map*)
       if (TAB == 2) part = linearize(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, SampledSource{tab, off, rmax, Xc, N, a.n_samples, M, a.samp_w, kpl.ego_front, kpl.ego_rear,
-                                                     sqrt(1.0 + 64.0 / kpl.q2_front), sqrt(1.0 + 64.0 / kpl.q2_rear)}, unc);
-      else part = linearize(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, TabSource{tab, wts, N, kpl.w_obstacle}, unc);
+                                                     sqrt(1.0 + 64.0 / kpl.q2_front), sqrt(1.0 + 64.0 / kpl.q2_rear)}, unc, upose, b);
+      else part = linearize(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, TabSource{tab, wts, N, kpl.w_obstacle}, unc, upose, b);
       J_new = readfirstlane_f64(wave_sum(part));
     }
     j_valid = true;
@@ -563,31 +572,35 @@ __global__ void quu_inverse_kernel(int n, const double* q, const double* lamb, d
 __global__ void unc_cost_kernel(UncArgs u, int n, const double* states, double* cost, double* vx, double* mx) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const UncProbe q = make_unc_probe(u, 0);
+  const UncPose po = unc_pose(u, 0);
   const double* st = states + 4 * (size_t)i;
   double sn, cs;
   sincos_fast(st[3], &sn, &cs);
   double g0 = 0.0, g1 = 0.0, h00 = 0.0, h01 = 0.0, h11 = 0.0;
-  const double c = q(st[0], st[1], cs, sn, g0, g1, h00, h01, h11);
-  const double inv = q.scale != 0.0 ? 1.0 / (q.scale * (double)(q.nl * q.nw)) : 0.0;  // undo w_uncertainty: report the bare cost terms
+  const double c = unc_cost_add(u, po, 0, st[0], st[1], cs, sn, g0, g1, h00, h01, h11);
+  const double inv = u.scale != 0.0 ? 1.0 / (u.scale * (double)(u.nl * u.nw)) : 0.0;  // undo w_uncertainty: report the bare cost terms
   cost[i] = c;
   vx[2 * i] = g0 * inv; vx[2 * i + 1] = g1 * inv;
   mx[3 * i] = h00 * inv; mx[3 * i + 1] = h01 * inv; mx[3 * i + 2] = h11 * inv;
 }
 
-template <bool DIAG, int TAB>
-hipError_t launch_pair(const SolveArgs& a, size_t lds, hipStream_t stream) {
+template <bool DIAG, int TAB, bool UNC>
+hipError_t launch_pair_unc(const SolveArgs& a, size_t lds, hipStream_t stream) {
   if (lds > 64 * 1024) {  // long horizons: opt in to more than the default 64 KiB of dynamic LDS (the CU has 160 KiB)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cilqr_solve_kernel<DIAG, TAB, false>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cilqr_solve_kernel<DIAG, TAB, false, UNC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cilqr_solve_kernel<DIAG, TAB, true>),
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cilqr_solve_kernel<DIAG, TAB, true, UNC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, TAB, false>), dim3(a.B), dim3(WAVE), lds, stream, a);
-  hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, TAB, true>), dim3(a.B), dim3(WAVE), lds, stream, a);
+  hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, TAB, false, UNC>), dim3(a.B), dim3(WAVE), lds, stream, a);
+  hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, TAB, true, UNC>), dim3(a.B), dim3(WAVE), lds, stream, a);
   return hipGetLastError();
+}
+template <bool DIAG, int TAB>
+hipError_t launch_pair(const SolveArgs& a, size_t lds, hipStream_t stream) {
+  return a.unc.layer ? launch_pair_unc<DIAG, TAB, true>(a, lds, stream) : launch_pair_unc<DIAG, TAB, false>(a, lds, stream);
 }
 
 }  // namespace

@@ -90,7 +90,8 @@ __device__ __forceinline__ void stage_wait() { asm volatile("s_waitcnt vmcnt(0)"
 
 // ---- the production kernel ---------------------------------------------------------------------------------------------------
 // chunk_r: steps per L→R hand-over chunk (a multiple of G); chunk_f: steps per forward-pass staging chunk (two buffers).
-template <int G>
+// UNC: an uncertainty map is set — a separate instantiation, so that without a map none of its code is in the kernel.
+template <int G, bool UNC>
 __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_fast(SolveArgs a, double* ws_base, int chunk_r, int chunk_f) {
   double* lds = cilqr_groups_lds;
   constexpr int S = WAVE / G;
@@ -175,6 +176,8 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_fast(SolveArgs a, dou
       }
     }
   }
+  UncPose upose{0, 0, 1, 0};
+  if (UNC && live) upose = unc_pose(a.unc, b);
   mem_sync();
   if (live) {  // nominal rollout, I/iLQR.cpp:51-62
     const double* x0 = a.x0 + (size_t)b * 4;
@@ -228,12 +231,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_fast(SolveArgs a, dou
           o.vn = xq[2 * S]; o.cn = xq[4 * S]; o.sn = xq[5 * S];
         };
         const KParams kpl = phase_params();  // this phase's own read of the parameter block (cilqr_device.hpp)
-        UncProbe probe;
-        const UncProbe* unc = nullptr;
-        if (aq->unc.layer) {  // a map is set (cilqr_set_uncertainty_map*): the same for every solve of the launch
-          probe = make_unc_probe(aq->unc, b);
-          unc = &probe;
-        }
+        const UncArgs* unc = UNC ? &aq->unc : nullptr;
         LIn cur, nxt;
         if (lo + g <= hi) load_in(cur, lo + g);
         for (int t = lo + g; t <= hi; t += G) {
@@ -251,12 +249,21 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_fast(SolveArgs a, dou
             return true;
           };
           Rec c;
-          Jpart += lin_step(kpl, cur.px, cur.py, cur.v, cur.ct, cur.st, cur.u0, cur.u1, cur.vn, cur.cn, cur.sn, cx, cy, M, obs, c, unc);
+          Jpart += lin_step(kpl, cur.px, cur.py, cur.v, cur.ct, cur.st, cur.u0, cur.u1, cur.vn, cur.cn, cur.sn, cx, cy, M, obs, c);
           double* r = lds + (size_t)(t - lo) * REC * S + grp;  // the record of step t, column grp of the chunk in LDS
           r[0] = c.lx0; r[S] = c.lx1; r[2 * S] = c.lx2; r[3 * S] = c.l00; r[4 * S] = c.l01; r[5 * S] = c.l11;
           r[6 * S] = c.lu0; r[7 * S] = c.lu1; r[8 * S] = c.luu0; r[9 * S] = c.luu1;
           r[10 * S] = c.al; r[11 * S] = c.be; r[12 * S] = c.ga; r[13 * S] = c.de; r[14 * S] = c.p; r[15 * S] = c.q;
           cur = nxt;
+        }
+        if (unc) {  // the map's term joins l_x, l_xx after the obstacles' (I/Constraints.cpp:188-201), in a loop of its own
+          for (int t = lo + g; t <= hi; t += G) {
+            const double* xr = &XF(xc, t, 0);
+            double* r = lds + (size_t)(t - lo) * REC * S + grp;
+            double lx0 = r[0], lx1 = r[S], h00 = r[3 * S], h01 = r[4 * S], h11 = r[5 * S];
+            unc_cost_add(*unc, upose, b, xr[0], xr[S], xr[4 * S], xr[5 * S], lx0, lx1, h00, h01, h11);
+            r[0] = lx0; r[S] = lx1; r[3 * S] = h00; r[4 * S] = h01; r[5 * S] = h11;
+          }
         }
       }
       __syncthreads();  // the chunk's records are in LDS (one wavefront per workgroup: this orders LDS traffic, it waits for nobody)
@@ -549,12 +556,9 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_general(SolveArgs a, 
   const bool faithful = (a.flags & CILQR_FLAG_FAITHFUL_ITERS) != 0;
   const int max_it = kp.max_iterations;
   const double dt = kp.dt, two_wvel = kp.w_vel * 2;
-  UncProbe probe;
-  const UncProbe* unc = nullptr;
-  if (a.unc.layer) {
-    probe = make_unc_probe(a.unc, b);
-    unc = &probe;
-  }
+  const UncArgs* unc = a.unc.layer ? &phase_args().unc : nullptr;
+  UncPose upose{0, 0, 1, 0};
+  if (unc) upose = unc_pose(a.unc, b);
   for (int it = 0; it < max_it; ++it) {
     ++iters;
     double Jpart = 0.0;
@@ -571,7 +575,8 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_general(SolveArgs a, 
       };
       Rec c;
       Jpart += lin_step(kp, px, py, XF(xc, t, 2), XF(xc, t, 4), XF(xc, t, 5), UF(uc, t, 0), UF(uc, t, 1), XF(xc, t + 1, 2),
-                        XF(xc, t + 1, 4), XF(xc, t + 1, 5), cx, cy, M, obs, c, unc);
+                        XF(xc, t + 1, 4), XF(xc, t + 1, 5), cx, cy, M, obs, c);
+      if (unc) unc_cost_add(*unc, upose, b, px, py, XF(xc, t, 4), XF(xc, t, 5), c.lx0, c.lx1, c.l00, c.l01, c.l11);
       double* r = &RF(t, 0);
       r[0] = c.lx0; r[S] = c.lx1; r[2 * S] = c.lx2; r[3 * S] = c.l00; r[4 * S] = c.l01; r[5 * S] = c.l11;
       r[6 * S] = c.lu0; r[7 * S] = c.lu1; r[8 * S] = c.luu0; r[9 * S] = c.luu1;
@@ -696,7 +701,8 @@ void launch_g(const SolveArgs& a, double* ws, hipStream_t stream) {
   const size_t lds = lds_r > lds_f ? lds_r : lds_f;
   const WsLayout L{a.N, a.M};
   double* rec_ws = ws + ((size_t)a.B + WAVE - 1) / WAVE * WAVE * (size_t)L.rows();  // behind the trajectory/gain blocks
-  hipLaunchKernelGGL((cilqr_solve_groups_fast<G>), dim3(blocks), dim3(WAVE), lds, stream, a, ws, chunk_r, chunk_f);
+  if (a.unc.layer) hipLaunchKernelGGL((cilqr_solve_groups_fast<G, true>), dim3(blocks), dim3(WAVE), lds, stream, a, ws, chunk_r, chunk_f);
+  else hipLaunchKernelGGL((cilqr_solve_groups_fast<G, false>), dim3(blocks), dim3(WAVE), lds, stream, a, ws, chunk_r, chunk_f);
   hipLaunchKernelGGL((cilqr_solve_groups_general<G>), dim3(blocks), dim3(WAVE), 0, stream, a, ws, rec_ws);
 }
 

@@ -144,12 +144,22 @@ __device__ __forceinline__ int index_axis(double p, double map_len, double map_p
   return (n > -2e9 && n < 2e9) ? (int)n : -1;
 }
 
+// EllipseIterator::isInside (G/grid_map_core/src/iterators/EllipseIterator.cpp:84-90) for cell (ii, jj), every operation
+// separate and the divisions carried out: the form the reference's compiler emits.
+__device__ __forceinline__ double inside_value_exact(double x_first, double y_first, double res, int ii, int jj, double Cx, double Cy,
+                                                     double cosR, double sinR, double semi0, double semi1) {
+#pragma clang fp contract(off)
+  const double dx = (x_first + res * (double)(-ii)) - Cx, dy = (y_first + res * (double)(-jj)) - Cy;
+  const double tx = cosR * dx + sinR * dy, ty = sinR * dx - cosR * dy;
+  return tx * tx / semi0 + ty * ty / semi1;
+}
+
 // LPC lanes per destination cell.  One lane per cell fills the chip from ≈ 65 k cells; the node's own map has 15 000, which
 // leaves three quarters of the SIMDs idle while each lane walks its ellipse alone — there four adjacent lanes share a cell
 // (rows of the ellipse's box dealt round-robin, the three sums combined by two shuffles; summation order changes by that).
 template <int LPC>
 __global__ __launch_bounds__(256) void blur_kernel(BlurArgs a) {
-#pragma clang fp contract(off)  // cell centres, the inside test and the weights as the reference's compiler forms them: no fma
+#pragma clang fp contract(off)  // cell centres, ellipse box and row offsets as the reference's compiler forms them: no fma
   const long n = (long)a.g.rows * a.g.cols;
   const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long lin = tid / LPC;
@@ -198,14 +208,23 @@ __global__ __launch_bounds__(256) void blur_kernel(BlurArgs a) {
     for (int ii = max(i0, 0) + sub; ii <= i1; ii += LPC) {
       const double dx = (x_first + res * (double)(-ii)) - Cx;
       for (int jj = max(j0, 0); jj <= j1; ++jj) {
-        const double dy = (y_first + res * (double)(-jj)) - Cy;
-        const double tx = cosR * dx + sinR * dy, ty = sinR * dx - cosR * dy;
-        double value = tx * tx * r0 + ty * ty * r1;
-        if (fabs(value - 1.0) < 1e-9) value = tx * tx / semi0 + ty * ty / semi1;  // the reference's own form, at the edge
+        double dy, value;
+        {
+#pragma clang fp contract(fast)  // the hot test, fused: decides membership only when it is clear of the boundary
+          dy = (y_first + res * (double)(-jj)) - Cy;
+          const double tx = cosR * dx + sinR * dy, ty = sinR * dx - cosR * dy;
+          value = tx * tx * r0 + ty * ty * r1;
+        }
+        // within 1e-9 of the boundary (fusing and the hoisted reciprocals move `value` by ≈1e-16): the reference's own form,
+        // unfused, with its divisions (EllipseIterator.cpp:84-90)
+        if (fabs(value - 1.0) < 1e-9) value = inside_value_exact(x_first, y_first, res, ii, jj, Cx, Cy, cosR, sinR, semi0, semi1);
         if (!(value <= 1)) continue;
-        const double f = pref * exp(kexp * (dx * dx * ixx - ixy * dx * dy + dy * dy * iyy));
-        numerator += f * (double)a.src[(size_t)jj * rows + ii];
-        denominator += f;
+        {
+#pragma clang fp contract(fast)  // the weights do not decide membership (the float32 output stays within the stated 1 ulp)
+          const double f = pref * exp(kexp * (dx * dx * ixx - ixy * dx * dy + dy * dy * iyy));
+          numerator += f * (double)a.src[(size_t)jj * rows + ii];
+          denominator += f;
+        }
         ++count;
       }
     }
