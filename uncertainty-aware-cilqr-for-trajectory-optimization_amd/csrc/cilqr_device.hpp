@@ -142,35 +142,35 @@ __device__ __forceinline__ State dyn_step(const KParams& kp, const State& st, do
 
 struct FwdConst {  // loop invariants of the forward pass, pinned in vector registers
   double dt, half_dt2, acc_max, acc_min, yaw_hi, yaw_lo, speed_max, zero;
-  double two_over_pi, p1, p2, p3, s1, s2, s3, s4, s5, s6, c1, c2, c3, c4, c5, c6;
+  double sn1, sn2, sn3, sn4, sn5, cs1, cs2, cs3, cs4, cs5, cs6;  // Taylor coefficients of sin d / d and (cos d - 1) / d², by powers of d²
 };
 __device__ __forceinline__ void make_fwd_const(FwdConst& k, const KParams& kp) {
   k.dt = kp.dt; k.half_dt2 = kp.half_dt2; k.acc_max = kp.acc_max; k.acc_min = kp.acc_min;
   k.yaw_hi = kp.yaw_hi; k.yaw_lo = kp.yaw_lo; k.speed_max = kp.speed_max; k.zero = 0.0;
-  k.two_over_pi = 6.36619772367581382433e-01;
-  k.p1 = 1.57079632679489655800e+00; k.p2 = 6.12323399573676603587e-17; k.p3 = -1.49738490485916983278e-33;
-  k.s1 = -1.66666666666666324348e-01; k.s2 = 8.33333333332248946124e-03; k.s3 = -1.98412698298579493134e-04;
-  k.s4 = 2.75573137070700676789e-06; k.s5 = -2.50507602534068634195e-08; k.s6 = 1.58969099521155010221e-10;
-  k.c1 = 4.16666666666666019037e-02; k.c2 = -1.38888888888741095749e-03; k.c3 = 2.48015872894767294178e-05;
-  k.c4 = -2.75573143513906633035e-07; k.c5 = 2.08757232129817482790e-09; k.c6 = -1.13596475577881948265e-11;
+  k.sn1 = -1.0 / 6.0; k.sn2 = 1.0 / 120.0; k.sn3 = -1.0 / 5040.0; k.sn4 = 1.0 / 362880.0; k.sn5 = -1.0 / 39916800.0;
+  k.cs1 = -0.5; k.cs2 = 1.0 / 24.0; k.cs3 = -1.0 / 720.0; k.cs4 = 1.0 / 40320.0; k.cs5 = -1.0 / 3628800.0; k.cs6 = 1.0 / 479001600.0;
   CILQR_PIN(k.dt); CILQR_PIN(k.half_dt2); CILQR_PIN(k.acc_max); CILQR_PIN(k.acc_min); CILQR_PIN(k.yaw_hi);
-  CILQR_PIN(k.yaw_lo); CILQR_PIN(k.speed_max); CILQR_PIN(k.zero); CILQR_PIN(k.two_over_pi);
-  CILQR_PIN(k.p1); CILQR_PIN(k.p2); CILQR_PIN(k.p3);
-  CILQR_PIN(k.s1); CILQR_PIN(k.s2); CILQR_PIN(k.s3); CILQR_PIN(k.s4); CILQR_PIN(k.s5); CILQR_PIN(k.s6);
-  CILQR_PIN(k.c1); CILQR_PIN(k.c2); CILQR_PIN(k.c3); CILQR_PIN(k.c4); CILQR_PIN(k.c5); CILQR_PIN(k.c6);
+  CILQR_PIN(k.yaw_lo); CILQR_PIN(k.speed_max); CILQR_PIN(k.zero);
+  CILQR_PIN(k.sn1); CILQR_PIN(k.sn2); CILQR_PIN(k.sn3); CILQR_PIN(k.sn4); CILQR_PIN(k.sn5);
+  CILQR_PIN(k.cs1); CILQR_PIN(k.cs2); CILQR_PIN(k.cs3); CILQR_PIN(k.cs4); CILQR_PIN(k.cs5); CILQR_PIN(k.cs6);
 }
 
-// sincos_fast without its range guard and with every constant in a register (same arithmetic, same results for
-// |x| < 1e6; callers track max|x| and hand the solve to the GENERAL kernel if that bound was ever exceeded).
-__device__ __forceinline__ void sincos_loop(const FwdConst& k, double x, double& sn, double& cs) {
-  const double n = rint(x * k.two_over_pi);
-  double r = fma(-n, k.p1, x);
-  r = fma(-n, k.p2, r);
-  r = fma(-n, k.p3, r);
+// sincos_fast without its range guard (same arithmetic, same results for |x| < 1e6; callers track max|x| and hand the solve to
+// the GENERAL kernel if that bound was ever exceeded).  Off the per-step chain since the headings are advanced by rotation
+// (rotate_heading): used for a trajectory's first state and for turns of more than 1/4 rad per step.
+__device__ __forceinline__ void sincos_loop(double x, double& sn, double& cs) {
+  const double n = rint(x * 6.36619772367581382433e-01);
+  double r = fma(-n, 1.57079632679489655800e+00, x);
+  r = fma(-n, 6.12323399573676603587e-17, r);
+  r = fma(-n, -1.49738490485916983278e-33, r);
   const double z = r * r;
-  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, k.s6, k.s5), k.s4), k.s3), k.s2), k.s1);
+  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                               2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                               8.33333333332248946124e-03), -1.66666666666666324348e-01);
   const double sr = fma(z * r, ps, r);
-  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, k.c6, k.c5), k.c4), k.c3), k.c2), k.c1);
+  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                               -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                               -1.38888888888741095749e-03), 4.16666666666666019037e-02);
   const double hz = 0.5 * z;
   const double w = 1.0 - hz;
   const double cr = w + (((1.0 - w) - hz) + z * (z * pc));
@@ -183,28 +183,55 @@ __device__ __forceinline__ void sincos_loop(const FwdConst& k, double x, double&
   cs = __hiloint2double(__double2hiint(c0) ^ sgc, __double2loint(c0));
 }
 
-// Model::forward_simulate on the in-loop constants.
-__device__ __forceinline__ void dyn_step_loop(const FwdConst& k, State& s, double u0, double u1, double& max_th) {
+// cos and sin of the heading advanced by a small turn: (c, s) rotated by delta = w·dt through the addition formulas, with sin
+// delta and cos delta from their Taylor series (|delta| ≤ 1/4: truncation below 2e-18 relative) — 17 branch-free instructions
+// instead of the 35 of a range-reduced sincos of the new heading, on the serial chain of every forward step.  The rounding of
+// each rotation (≈1e-16) accumulates over the horizon instead of being redone from the rounded angle: ≈1e-15 after 80 steps,
+// far inside the parity tolerance.  Callers track the largest |delta| (MAX_TURN) and hand the solve to the GENERAL kernel —
+// which evaluates sincos of every heading — if a turn was larger (above 8 m/s at full lock with the reference's parameters); a
+// first heading beyond MAX_HEADING0 goes there too, so that |theta| stays in the range of sincos_loop over any horizon.
+constexpr double MAX_TURN = 0.25, MAX_HEADING0 = 9.99e5;
+__device__ __forceinline__ void rotate_heading(const FwdConst& k, double delta, double& sn, double& cs) {
+  const double z = delta * delta;
+  double ps = fma(z, k.sn5, k.sn4);  // sin d = d (1 - z/3! + z²/5! - z³/7! + z⁴/9! - z⁵/11!)
+  ps = fma(ps, z, k.sn3);
+  ps = fma(ps, z, k.sn2);
+  ps = fma(ps, z, k.sn1);
+  const double sd = fma(delta * z, ps, delta);
+  double pc = fma(z, k.cs6, k.cs5);  // cos d - 1 = z (-1/2 + z/4! - z²/6! + z³/8! - z⁴/10! + z⁵/12!)
+  pc = fma(pc, z, k.cs4);
+  pc = fma(pc, z, k.cs3);
+  pc = fma(pc, z, k.cs2);
+  pc = fma(pc, z, k.cs1);
+  const double cdm1 = pc * z;
+  const double c0 = cs, s0 = sn;
+  cs = fma(c0, cdm1, fma(-s0, sd, c0));
+  sn = fma(s0, cdm1, fma(c0, sd, s0));
+}
+
+// Model::forward_simulate on the in-loop constants.  max_turn: running maximum of |w·dt| (see rotate_heading).
+__device__ __forceinline__ void dyn_step_loop(const FwdConst& k, State& s, double u0, double u1, double& max_turn) {
   const double a = vmax(vmin(u0, k.acc_max), k.acc_min);
   const double w = vmax(vmin(u1, s.v * k.yaw_hi), s.v * k.yaw_lo);
   const double adv = fma(a, k.half_dt2, s.v * k.dt);
   s.x = fma(s.c, adv, s.x);
   s.y = fma(s.s, adv, s.y);
   s.v = vmin(vmax(fma(a, k.dt, s.v), k.zero), k.speed_max);
-  s.th = fma(w, k.dt, s.th);
-  max_th = vmax(max_th, fabs(s.th));
-  sincos_loop(k, s.th, s.s, s.c);
+  const double delta = w * k.dt;
+  s.th = s.th + delta;
+  max_turn = vmax(max_turn, fabs(delta));
+  rotate_heading(k, delta, s.s, s.c);
 }
 
 // One step of iLQR::forward_pass (I/iLQR.cpp:77-85): old state (ox..oth), old control (ou0, ou1), gains g[10].
 struct FwdIn {
   double x, y, v, th, u0, u1, g[KR];
 };
-__device__ __forceinline__ void forward_step(const FwdConst& k, const FwdIn& c, State& s, double& max_th, double& u0, double& u1) {
+__device__ __forceinline__ void forward_step(const FwdConst& k, const FwdIn& c, State& s, double& max_turn, double& u0, double& u1) {
   const double d0 = s.x - c.x, d1 = s.y - c.y, d2 = s.v - c.v, d3 = s.th - c.th;
   u0 = fma(c.g[5], d3, fma(c.g[4], d2, fma(c.g[3], d1, fma(c.g[2], d0, c.u0 + c.g[0]))));
   u1 = fma(c.g[9], d3, fma(c.g[8], d2, fma(c.g[7], d1, fma(c.g[6], d0, c.u1 + c.g[1]))));
-  dyn_step_loop(k, s, u0, u1, max_th);
+  dyn_step_loop(k, s, u0, u1, max_turn);
 }
 
 // ---- path samples and the closest-point search -----------------------------------------------------------------------
@@ -624,10 +651,23 @@ __device__ __forceinline__ void riccati_step(const Rec& c, Value& V, double dt, 
   const double K12 = fma(-i01, ux02, -(i11 * ux12)), K13 = fma(-i01, ux03, -(i11 * ux13));
 
   // G = K' Q_uu (unregularised) ; V_x = Q_x - G k ; V_xx = Q_xx - G K (:180-181)
-  const double g00 = fma(K00, a, K10 * b), g01 = fma(K00, b, K10 * d);
-  const double g10 = fma(K01, a, K11 * b), g11 = fma(K01, b, K11 * d);
-  const double g20 = fma(K02, a, K12 * b), g21 = fma(K02, b, K12 * d);
-  const double g30 = fma(K03, a, K13 * b), g31 = fma(K03, b, K13 * d);
+  double g00, g01, g10, g11, g20, g21, g30, g31;
+  if (FAST) {
+    // In the positive-semi-definite case the regularised inverse is inv(Q_uu + lamb I) itself, so
+    //   Q_uu K = -(Q_uu + lamb I - lamb I) inv(Q_uu + lamb I) Q_ux = -Q_ux - lamb K,   i.e.  G = -(Q_ux + lamb K)':
+    // one fused multiply-add per entry instead of two products (8 instructions less on the serial chain of every step), and
+    // without the cancellation of the direct product (Q_uu K ≈ -Q_ux for small lamb).  Agrees with the reference's product to
+    // rounding; the GENERAL kernel, where clamped eigenvalues break the identity, keeps the product.
+    g00 = fma(-lamb, K00, -e00); g01 = fma(-lamb, K10, -e10);
+    g10 = fma(-lamb, K01, -e01); g11 = fma(-lamb, K11, -e11);
+    g20 = fma(-lamb, K02, -ux02); g21 = fma(-lamb, K12, -ux12);
+    g30 = fma(-lamb, K03, -ux03); g31 = fma(-lamb, K13, -ux13);
+  } else {
+    g00 = fma(K00, a, K10 * b); g01 = fma(K00, b, K10 * d);
+    g10 = fma(K01, a, K11 * b); g11 = fma(K01, b, K11 * d);
+    g20 = fma(K02, a, K12 * b); g21 = fma(K02, b, K12 * d);
+    g30 = fma(K03, a, K13 * b); g31 = fma(K03, b, K13 * d);
+  }
   V.x0 = fma(-g01, k1, fma(-g00, k0, qx0));
   V.x1 = fma(-g11, k1, fma(-g10, k0, qx1));
   V.x2 = fma(-g21, k1, fma(-g20, k0, qx2));

@@ -262,10 +262,10 @@ __device__ __forceinline__ void load_fwd(FwdIn& o, const double* X, const double
   for (int k = 0; k < KR; ++k) o.g[k] = g[k];
 }
 
-__device__ __forceinline__ void fwd_step_store(const FwdConst& k, const FwdIn& c, State& s, double& max_th, double* Un_i,
+__device__ __forceinline__ void fwd_step_store(const FwdConst& k, const FwdIn& c, State& s, double& max_turn, double* Un_i,
                                                double* Xn_next) {
   double u0, u1;
-  forward_step(k, c, s, max_th, u0, u1);
+  forward_step(k, c, s, max_turn, u0, u1);
   if (threadIdx.x == 0) {
     Un_i[0] = u0; Un_i[1] = u1;
     Xn_next[0] = s.x; Xn_next[1] = s.y; Xn_next[2] = s.v; Xn_next[3] = s.th; Xn_next[4] = s.c; Xn_next[5] = s.s;
@@ -274,8 +274,8 @@ __device__ __forceinline__ void fwd_step_store(const FwdConst& k, const FwdIn& c
 
 // Phase F: iLQR::forward_pass (I/iLQR.cpp:68-86).  All lanes compute the same values; lane 0 stores; the operands of
 // step i+1 (old state, old control, gains) are read while step i computes (two steps per trip, no register copies).
-// Returns false if a heading left the range of the in-loop sincos (|theta| ≥ 1e6 rad, or NaN): the results are then not
-// to be used and the solve is handed to the GENERAL kernel.
+// Returns false if a step turned the heading by more than MAX_TURN (rotate_heading, cilqr_device.hpp): the results are then
+// not to be used and the solve is handed to the GENERAL kernel.
 __device__ __forceinline__ bool forward_fast(const KParams& kp, int N, const double* X, const double* U, const double* kK,
                                              double* Xn, double* Un) {
   FwdConst k;
@@ -283,18 +283,18 @@ __device__ __forceinline__ bool forward_fast(const KParams& kp, int N, const dou
   State s;
   s.x = X[0]; s.y = X[1]; s.v = X[2]; s.th = X[3]; s.c = X[4]; s.s = X[5];
   if (threadIdx.x == 0) store_state(Xn, 0, s);
-  double max_th = fabs(s.th);
+  double max_turn = 0.0;  // (the first heading was checked by the rollout)
   FwdIn fa, fb;
   load_fwd(fa, X, U, kK, 0);
   int i = 0;
   for (; i + 1 < N; i += 2) {
     load_fwd(fb, X, U, kK, i + 1);
-    fwd_step_store(k, fa, s, max_th, Un + 2 * i, Xn + (i + 1) * XR);
+    fwd_step_store(k, fa, s, max_turn, Un + 2 * i, Xn + (i + 1) * XR);
     load_fwd(fa, X, U, kK, i + 2 < N ? i + 2 : i + 1);
-    fwd_step_store(k, fb, s, max_th, Un + 2 * (i + 1), Xn + (i + 2) * XR);
+    fwd_step_store(k, fb, s, max_turn, Un + 2 * (i + 1), Xn + (i + 2) * XR);
   }
-  if (i < N) fwd_step_store(k, fa, s, max_th, Un + 2 * i, Xn + (i + 1) * XR);
-  return max_th < 1.0e6;
+  if (i < N) fwd_step_store(k, fa, s, max_turn, Un + 2 * i, Xn + (i + 1) * XR);
+  return max_turn <= MAX_TURN;
 }
 
 // The same pass with the range-guarded sincos (library path for huge arguments); GENERAL kernel only.
@@ -324,14 +324,15 @@ __device__ __forceinline__ bool rollout_fast(const KParams& kp, int N, const dou
   make_fwd_const(k, kp);
   State s;
   s.x = x0[0]; s.y = x0[1]; s.v = x0[2]; s.th = x0[3];
-  double max_th = fabs(s.th);
-  sincos_loop(k, s.th, s.s, s.c);
+  const bool th0_ok = fabs(s.th) < MAX_HEADING0;
+  double max_turn = 0.0;
+  sincos_loop(s.th, s.s, s.c);
   if (threadIdx.x == 0) store_state(X, 0, s);
   for (int i = 0; i < N; ++i) {
-    dyn_step_loop(k, s, U[2 * i], U[2 * i + 1], max_th);
+    dyn_step_loop(k, s, U[2 * i], U[2 * i + 1], max_turn);
     if (threadIdx.x == 0) store_state(X, i + 1, s);
   }
-  return max_th < 1.0e6;
+  return th0_ok && max_turn <= MAX_TURN;
 }
 
 // DIAG: per-solve shader-clock totals by phase, written to a.diag[b][8] = {prologue, L, R, F, epilogue, L count, R count,

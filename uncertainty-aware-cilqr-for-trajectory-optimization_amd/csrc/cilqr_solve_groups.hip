@@ -185,14 +185,15 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_fast(SolveArgs a, dou
     s.x = x0[0]; s.y = x0[1]; s.v = x0[2]; s.th = x0[3];
     FwdConst k;
     make_fwd_const(k, kp);
-    double max_th = fabs(s.th);
-    sincos_loop(k, s.th, s.s, s.c);
+    const bool th0_ok = fabs(s.th) < MAX_HEADING0;
+    double max_turn = 0.0;
+    sincos_loop(s.th, s.s, s.c);
     store_state(L.xa(), 0, s);
     for (int i = 0; i < N; ++i) {
-      dyn_step_loop(k, s, UF(L.ua(), i, 0), UF(L.ua(), i, 1), max_th);
+      dyn_step_loop(k, s, UF(L.ua(), i, 0), UF(L.ua(), i, 1), max_turn);
       store_state(L.xa(), i + 1, s);
     }
-    handover = !(max_th < 1.0e6);
+    handover = !(th0_ok && max_turn <= MAX_TURN);
   }
   mem_sync();
 
@@ -341,17 +342,16 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_fast(SolveArgs a, dou
       s.x = 0; s.y = 0; s.v = 0; s.th = 0; s.c = 1; s.s = 0;
       FwdConst k;
       make_fwd_const(k, KParams(phase_params()));
-      double max_th = 0.0;
+      double max_turn = 0.0;
       auto step = [&](const FwdIn& c, int i) {
         double u0, u1;
-        forward_step(k, c, s, max_th, u0, u1);
+        forward_step(k, c, s, max_turn, u0, u1);
         if (g == 0) { double* ur = &UF(un, i, 0); ur[0] = u0; ur[S] = u1; }
         store_state(xn, i + 1, s);
       };
       if (active) {
         s.x = XF(xc, 0, 0); s.y = XF(xc, 0, 1); s.v = XF(xc, 0, 2); s.th = XF(xc, 0, 3); s.c = XF(xc, 0, 4); s.s = XF(xc, 0, 5);
         store_state(xn, 0, s);
-        max_th = fabs(s.th);
       }
       if (faithful) {
         // With CILQR_FLAG_FAITHFUL_ITERS a solve that has rejected keeps iterating without swapping its trajectory buffers
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_fast(SolveArgs a, dou
           buf ^= 1;
         }
       }
-      if (active && !(max_th < 1.0e6)) { handover = true; active = false; }
+      if (active && !(max_turn <= MAX_TURN)) { handover = true; active = false; }
     }
     mem_sync();
     if (a.diag && active) tF += __builtin_readcyclecounter() - t0;
