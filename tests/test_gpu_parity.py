@@ -262,6 +262,44 @@ def test_general_kernel_paths(cilqr, oracle, solver):
     assert np.array_equal(got["U"][keep], base["U"][keep])
 
 
+@pytest.mark.parametrize("G", [0, 8])
+def test_large_turns_hand_over_to_general_kernel(cilqr, oracle, G, monkeypatch):
+    """The production kernels advance the heading's cos/sin by rotation, valid for turns up to 1/4 rad per step
+    (rotate_heading, cilqr_device.hpp); a solve that turns faster anywhere must be redone by the GENERAL kernel.  Fast egos
+    (10-25 m/s) with a full-lock warm start turn 0.3-0.8 rad per step: they must still follow the oracle, in both families,
+    and the ordinary solves beside them in the batch keep their bits; a pass-count buffer shows who handed over."""
+    import torch
+    from cilqr_amd import scenes
+    if G:
+        monkeypatch.setenv("CILQR_FORCE_G", str(G))
+    N, M, B = 50, 2, 48
+    p = cilqr.default_params(N)
+    sc = scenes.make_static(B, N, M, p, 8111)
+    s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M, device=0)
+    try:
+        base = _gpu_batch(s, sc)
+        fast = dict(sc, x0=sc["x0"].copy(), U=sc["U"].copy())
+        rng = np.random.default_rng(8112)
+        hot = np.arange(0, B, 3)
+        fast["x0"][hot, 2] = rng.uniform(10.0, 25.0, hot.size)
+        Uh = fast["U"].reshape(B, N, 2)
+        Uh[hot, :, 1] = np.where(rng.random((hot.size, 1)) < 0.5, 8.0, -8.0)  # clamped to ±v·tan(steer_max)/L inside the model
+        got = _gpu_batch(s, fast)
+    finally:
+        s.close()
+    want = _oracle_batch(oracle, N, fast)
+    ok = np.isfinite(want["U"]).all(axis=1)
+    assert ok[hot].sum() >= hot.size // 2
+    _compare({k: v[ok] for k, v in got.items()}, {k: v[ok] for k, v in want.items()}, 1e-8, "large turns G=%d" % G)
+    assert np.array_equal(got["status"][~ok], want["status"][~ok]) and np.array_equal(got["iters"][~ok], want["iters"][~ok])
+    cold = np.setdiff1d(np.arange(B), hot)
+    for k in ("U", "X", "J", "iters", "status"):
+        assert np.array_equal(got[k][cold], base[k][cold]), k
+    # the turn really exceeded the bound on the hot solves' first rollout
+    yaw_hi = np.tan(p.steer_angle_max) / p.wheelbase
+    assert (fast["x0"][hot, 2] * yaw_hi * p.timestep > 0.25).all()
+
+
 def test_quu_inverse_branches_vs_reference_eigensolver(cilqr, solver):
     """The kernels' regularised Q_uu inverse against the reference's own EigenSolver path (tests/golden/ref_quu.json,
     generated from the vendored Eigen): the eigenvalue-CLAMPING branch of the GENERAL kernel on the indefinite matrices, and
