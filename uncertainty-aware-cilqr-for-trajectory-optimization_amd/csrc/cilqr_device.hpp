@@ -599,9 +599,20 @@ __device__ __forceinline__ void riccati_step(const Rec& c, Value& V, double dt, 
   // Q_x = l_x + fx V_x ; Q_u = l_u + fu V_x (:149-150)
   const double qx0 = c.lx0 + x0;
   const double qx1 = c.lx1 + x1;
-  const double qx2 = fma(al, x0, fma(be, x1, x2 + c.lx2));
   const double qx3 = fma(ga, x0, fma(de, x1, x3));
-  const double qu0 = fma(p, x0, fma(q, x1, fma(dt, x2, c.lu0)));
+  double qx2, qu0;
+  if (FAST) {
+    // Row 0 of fu is (p, q, dt, 0) = (dt/2)·(row 2 of fx + e_2) — p = (dt/2)·al, q = (dt/2)·be by their definitions
+    // (I/Model.cpp:139-155 against :100-127) — so every product with it follows from the matching row-2 product of fx with one
+    // add and one multiply instead of three multiply-adds: here, and for E's first row and Q_uu(0,0) below (6 instructions per
+    // step in all; equal to the direct products to rounding).
+    const double s2 = fma(al, x0, fma(be, x1, x2));
+    qx2 = s2 + c.lx2;
+    qu0 = fma(0.5 * dt, s2 + x2, c.lu0);
+  } else {
+    qx2 = fma(al, x0, fma(be, x1, x2 + c.lx2));
+    qu0 = fma(p, x0, fma(q, x1, fma(dt, x2, c.lu0)));
+  }
   const double qu1 = fma(dt, x3, c.lu1);
 
   // T = fx V (rows 2, 3) ; Q_xx = l_xx + T fx' (:151)
@@ -618,16 +629,22 @@ __device__ __forceinline__ void riccati_step(const Rec& c, Value& V, double dt, 
   const double q33 = fma(ga, t30, fma(de, t31, t33));
 
   // E = fu V ; Q_ux = E fx' ; Q_uu = l_uu + E fu' (:152-153)
-  const double e00 = fma(p, v00, fma(q, v01, dt * v02));
-  const double e01 = fma(p, v01, fma(q, v11, dt * v12));
-  const double e02 = fma(p, v02, fma(q, v12, dt * v22));
-  const double e03 = fma(p, v03, fma(q, v13, dt * v23));
+  double e00, e01, e02, e03;
+  if (FAST) {
+    const double hd = 0.5 * dt;  // e0j = (dt/2)·(t2j + v2j)
+    e00 = hd * (t20 + v02); e01 = hd * (t21 + v12); e02 = hd * (t22 + v22); e03 = hd * (t23 + v23);
+  } else {
+    e00 = fma(p, v00, fma(q, v01, dt * v02));
+    e01 = fma(p, v01, fma(q, v11, dt * v12));
+    e02 = fma(p, v02, fma(q, v12, dt * v22));
+    e03 = fma(p, v03, fma(q, v13, dt * v23));
+  }
   const double e10 = dt * v03, e11 = dt * v13, e12 = dt * v23, e13 = dt * v33;
   const double ux02 = fma(al, e00, fma(be, e01, e02));
   const double ux03 = fma(ga, e00, fma(de, e01, e03));
   const double ux12 = fma(al, e10, fma(be, e11, e12));
   const double ux13 = fma(ga, e10, fma(de, e11, e13));
-  const double a = fma(p, e00, fma(q, e01, fma(dt, e02, c.luu0)));
+  const double a = FAST ? fma(0.5 * dt, ux02 + e02, c.luu0) : fma(p, e00, fma(q, e01, fma(dt, e02, c.luu0)));
   const double b = dt * e03;
   const double d = fma(dt, e13, c.luu1);
 
