@@ -1563,3 +1563,34 @@ def test_warp_batch_equals_single_frames(cilqr, oracle):
                 assert np.array_equal(single, want, equal_nan=True) and soob == woob
     finally:
         s.close()
+
+
+def test_sampled_obstacles_with_changing_shape(cilqr, oracle):
+    """The compact sampled form derives a sample's heading and semi-axes once per solve when its obstacle keeps heading, speed
+    and dimensions over the horizon, and per entry otherwise.  Here one obstacle turns, one brakes, one grows and one is
+    steady — in the same solve — against the oracle on the materialised scene (1e-8: angle addition, reciprocal semi-axes)."""
+    from cilqr_amd import scenes
+    N, B, n_dyn, S = 50, 40, 4, 6
+    p = cilqr.default_params(N)
+    sc = scenes.make_c3(B, p, n_dyn=n_dyn, n_samples=S)
+    nom = sc["nom_pose"].reshape(B, n_dyn, N, 4).copy()
+    dim = sc["nom_dim"].reshape(B, n_dyn, N, 2).copy()
+    t = np.arange(N)
+    nom[:, 0, :, 3] += 0.01 * t                       # turning
+    nom[:, 1, :, 2] *= np.linspace(1.0, 0.3, N)       # braking
+    dim[:, 2, N // 2:, 0] += 0.5                      # grows half-way
+    off = sc["offsets"]
+    poses = np.repeat(nom[:, :, None, :, :], S, axis=2)
+    poses[..., 0] += off[..., 0][..., None]
+    poses[..., 1] += off[..., 1][..., None]
+    poses[..., 3] += off[..., 2][..., None]
+    dims = np.repeat(dim[:, :, None, :, :], S, axis=2)
+    M = n_dyn * S
+    mat = dict(sc, M=M, obs_pose=poses.reshape(B, M, 4 * N), obs_dim=dims.reshape(B, M, 2 * N))
+    s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M, device=0)
+    try:
+        got = s.solve_batch_sampled(N, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], nom.reshape(B, n_dyn, 4 * N), dim.reshape(B, n_dyn, 2 * N),
+                                    off, sc["sample_weight"])
+    finally:
+        s.close()
+    _compare(got, _oracle_batch(oracle, N, mat), 1e-8, "sampled, changing shape")

@@ -10,7 +10,8 @@
 //
 // Mapping: workgroup = one 64-lane wavefront = one solve, whole ≤20-iteration loop inside one
 // launch.  Everything a solve touches between its first load and its last store lives in LDS:
-//   samp  [S][2]        the S = 200 path samples (depend only on poly / x_local_plan, I/Constraints.cpp:28-42)
+//   samp  [S]           ordinates of the S = 200 path samples (they depend only on poly / x_local_plan, I/Constraints.cpp:28-42;
+//                       the abscissae are equispaced and re-formed with one fma where needed)
 //   X a/b [(N+1)][6]    state records {x, y, v, theta, cos theta, sin theta}, double-buffered (X / X_new)
 //   U a/b [N][2]        controls, double-buffered (U / U_new)
 //   rec   [N][16]       per-step linearisation {l_x(3), l_xx(3), l_u(2), l_uu(2), A/B entries(6)}
@@ -54,9 +55,10 @@ __device__ __forceinline__ void store_state(double* X, int t, const State& s) {
   r[0] = s.x; r[1] = s.y; r[2] = s.v; r[3] = s.th; r[4] = s.c; r[5] = s.s;
 }
 
-struct LdsSamples {  // sample accessor over the LDS copy
+struct LdsSamples {  // sample accessor over the LDS copy: ordinate stored, abscissa re-formed exactly as sample_xy forms it
   const double* samp;
-  __device__ __forceinline__ void operator()(int s, double& x, double& y) const { x = samp[2 * s]; y = samp[2 * s + 1]; }
+  double xf, dxs;
+  __device__ __forceinline__ void operator()(int s, double& x, double& y) const { x = fma(dxs, (double)s, xf); y = samp[s]; }
 };
 
 struct TabObstacles {  // obstacle accessor over the [m][t][field] table (LDS or global)
@@ -90,7 +92,7 @@ struct TabSource {  // every obstacle has its own table row
 // (o, t)) stay in global memory and are read once per obstacle and iteration; the offset records live in LDS and are read
 // at a wave-uniform address.  cos/sin of the sample heading come from the angle-addition formulas.
 constexpr int NOMF = 8;  // x, y, cos, sin, v·t_safe, half-length + margins, half-width + margins, pad
-constexpr int OFFF = 4;  // dx, dy, cos(dtheta), sin(dtheta)
+constexpr int OFFF = 6;  // dx, dy, then (cos, sin of the SAMPLE's heading, 1/a², 1/b²) for an obstacle of constant shape, else (cos dtheta, sin dtheta, -, -)
 struct SampledObstacles {
   const double* nom;  // this lane's step: record of obstacle 0; obstacle stride N·NOMF
   const double* off;  // LDS [o][s][OFFF]
@@ -98,7 +100,8 @@ struct SampledObstacles {
   double w;
   int o, s;
   bool far;                                // the obstacle in use is negligible at every step of this wavefront (see below)
-  const double* rmax;                      // LDS [o]: largest |(dx, dy)| over the obstacle's samples
+  const double* rmax;                      // LDS [o]: largest |(dx, dy)| over the obstacle's samples; then [n_obs + o]: constant-shape flag
+  bool cshape;                             // the obstacle in use keeps heading, speed and dimensions over the horizon (see the prologue)
   double fx, fy, rx, ry, kf, kr;           // this step's two ego circle centres; sqrt(1 + 64/q2) for either circle
   double x, y, c0, s0, vt, ha, hb;         // nominal record in use
   double nx, ny, nc0, ns0, nvt, nha, nhb;  // the next obstacle's, requested one obstacle (S entries) ahead
@@ -122,6 +125,7 @@ struct SampledObstacles {
       const double tf = (R + A * kf) * (1.0 + 1.0e-9), tr = (R + A * kr) * (1.0 + 1.0e-9);
       const bool is_far = df >= tf * tf && dr >= tr * tr;  // false for NaN
       far = __builtin_amdgcn_ballot_w64(!is_far) == 0;
+      cshape = rmax[n_obs + o] != 0.0;  // wave-uniform
     }
     if (far) {
       if (++s == S) { s = 0; ++o; }
@@ -129,11 +133,16 @@ struct SampledObstacles {
     }
     const double2* q = reinterpret_cast<const double2*>(off + ((size_t)o * S + s) * OFFF);
     const double2 d = q[0], r = q[1];
-    e.co = c0 * r.x - s0 * r.y;
-    e.so = s0 * r.x + c0 * r.y;
-    const double ra = rcp_newton(ha + fabs(vt * e.co)), rb = rcp_newton(hb + fabs(vt * e.so));  // I/Obstacle.cpp:42-43
-    e.ia2 = ra * ra;
-    e.ib2 = rb * rb;
+    if (cshape) {  // heading, semi-axes of this sample do not depend on the step: formed once per solve in the prologue
+      const double2 u = q[2];
+      e.co = r.x; e.so = r.y; e.ia2 = u.x; e.ib2 = u.y;
+    } else {
+      e.co = c0 * r.x - s0 * r.y;
+      e.so = s0 * r.x + c0 * r.y;
+      const double ra = rcp_newton(ha + fabs(vt * e.co)), rb = rcp_newton(hb + fabs(vt * e.so));  // I/Obstacle.cpp:42-43
+      e.ia2 = ra * ra;
+      e.ib2 = rb * rb;
+    }
     e.ox = x + d.x;
     e.oy = y + d.y;
     wout = w;
@@ -151,7 +160,7 @@ struct SampledSource {
   __device__ __forceinline__ SampledObstacles at(int t) const {
     SampledObstacles a;
     a.nom = nom + (size_t)t * NOMF; a.off = off; a.N = N; a.S = S; a.n_obs = n_obs; a.w = w;
-    a.o = 0; a.s = 0; a.far = false; a.rmax = rmax;
+    a.o = 0; a.s = 0; a.far = false; a.cshape = false; a.rmax = rmax;
     const double* xr = X + t * XR;
     a.fx = xr[0] + xr[4] * ego_front; a.fy = xr[1] + xr[5] * ego_front;
     a.rx = xr[0] - xr[4] * ego_rear; a.ry = xr[1] - xr[5] * ego_rear;
@@ -171,10 +180,10 @@ __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int
     const double* xr = X + t * XR;
     const double* xn = X + (t + 1) * XR;
     const double px = xr[0], py = xr[1];
-    const int cs = closest_sample(S, grid, px, py, LdsSamples{samp});
+    const int cs = closest_sample(S, grid, px, py, LdsSamples{samp, grid.xf, grid.dxs});
     Rec c;
-    Jpart += lin_step<true>(kp, px, py, xr[2], xr[4], xr[5], U[2 * t], U[2 * t + 1], xn[2], xn[4], xn[5], samp[2 * cs],
-                      samp[2 * cs + 1], M, src.at(t), c);
+    Jpart += lin_step<true>(kp, px, py, xr[2], xr[4], xr[5], U[2 * t], U[2 * t + 1], xn[2], xn[4], xn[5], fma(grid.dxs, (double)cs, grid.xf),
+                      samp[cs], M, src.at(t), c);
     double* r = rec + t * REC;
     r[0] = c.lx0; r[1] = c.lx1; r[2] = c.lx2; r[3] = c.l00; r[4] = c.l01; r[5] = c.l11;
     r[6] = c.lu0; r[7] = c.lu1; r[8] = c.luu0; r[9] = c.luu1;
@@ -198,8 +207,8 @@ __device__ __forceinline__ double cost_only(const KParams& kp, int N, int lane, 
   double Jpart = 0.0;
   for (int t = lane; t < N; t += WAVE) {
     const double* xr = X + t * XR;
-    const int cs = closest_sample(S, grid, xr[0], xr[1], LdsSamples{samp});
-    Jpart += stage_cost(kp, xr[0] - samp[2 * cs], xr[1] - samp[2 * cs + 1], xr[2] - kp.desired_speed, U[2 * t], U[2 * t + 1]);
+    const int cs = closest_sample(S, grid, xr[0], xr[1], LdsSamples{samp, grid.xf, grid.dxs});
+    Jpart += stage_cost(kp, xr[0] - fma(grid.dxs, (double)cs, grid.xf), xr[1] - samp[cs], xr[2] - kp.desired_speed, U[2 * t], U[2 * t + 1]);
   }
   return Jpart;
 }
@@ -367,7 +376,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   if (GENERAL && a.redo[b] == 0) return;
 
   double* samp = lds;
-  double* Xa = samp + 2 * S;
+  double* Xa = samp + ((S + 1) & ~1);  // (even count: the records behind stay 16-byte aligned)
   double* Xb = Xa + (N + 1) * XR;
   double* Ua = Xb + (N + 1) * XR;
   double* Ub = Ua + 2 * N;
@@ -382,7 +391,10 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   make_sample_grid(grid, a.xplan_fl[2 * b], a.xplan_fl[2 * b + 1], S);
   {
     const double* pc = a.poly + (size_t)b * CILQR_POLY_COEFFS;
-    for (int s = lane; s < S; s += WAVE) sample_xy(grid, pc, s, samp[2 * s], samp[2 * s + 1]);
+    for (int s = lane; s < S; s += WAVE) {
+      double xs;
+      sample_xy(grid, pc, s, xs, samp[s]);
+    }
   }
   double* Ug = a.U + (size_t)b * 2 * N;
   for (int i = lane; i < 2 * N; i += WAVE) Ua[i] = Ug[i];
@@ -402,13 +414,44 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
         o[7] = 0.0;
       }
     }
+    // An obstacle that keeps its heading, speed and dimensions over the horizon (a vehicle driving straight: every obstacle of
+    // the benchmark) gives each of its samples a heading and semi-axes that do not depend on the step: they are derived here,
+    // once per solve (same arithmetic as the per-entry derivation in SampledObstacles: bit-identical results), instead of 22
+    // instructions per entry, step and iteration.  Flag per obstacle behind rmax.
+    for (int m = 0; m < M; ++m) {
+      bool same = true;
+      const double* pose0 = a.obs_pose + ((size_t)b * M + m) * N * 4;
+      const double* dim0 = a.obs_dim + ((size_t)b * M + m) * N * 2;
+      for (int t = lane; t < N; t += WAVE) {
+        const double* pose = pose0 + (size_t)t * 4;
+        const double* dim = dim0 + (size_t)t * 2;
+        same = same && pose[2] == pose0[2] && pose[3] == pose0[3] && dim[0] == dim0[0] && dim[1] == dim0[1];
+      }
+      const bool all_same = __builtin_amdgcn_ballot_w64(!same) == 0;
+      if (lane == 0) rmax[M + m] = all_same ? 1.0 : 0.0;
+    }
+    __syncthreads();
     const int n_off = M * a.n_samples;
     for (int i = lane; i < n_off; i += WAVE) {
       const double* q = a.samp_off + ((size_t)b * n_off + i) * 3;
       double sn, cs;
       sincos(q[2], &sn, &cs);
       double* o = off + (size_t)i * OFFF;
-      o[0] = q[0]; o[1] = q[1]; o[2] = cs; o[3] = sn;
+      o[0] = q[0]; o[1] = q[1];
+      const int m = i / a.n_samples;
+      if (rmax[M + m] != 0.0) {
+        const double* pose0 = a.obs_pose + ((size_t)b * M + m) * N * 4;
+        const double* dim0 = a.obs_dim + ((size_t)b * M + m) * N * 2;
+        double s0, c0;
+        sincos(pose0[3], &s0, &c0);  // the nominal record's own cos / sin
+        const double vt = pose0[2] * kp.t_safe;
+        const double ha = dim0[0] / 2.0 + kp.s_safe_a + kp.ego_rad, hb = dim0[1] / 2.0 + kp.s_safe_b + kp.ego_rad + 1;
+        const double co = c0 * cs - s0 * sn, so = s0 * cs + c0 * sn;
+        const double ra = rcp_newton(ha + fabs(vt * co)), rb = rcp_newton(hb + fabs(vt * so));  // I/Obstacle.cpp:42-43
+        o[2] = co; o[3] = so; o[4] = ra * ra; o[5] = rb * rb;
+      } else {
+        o[2] = cs; o[3] = sn; o[4] = 0.0; o[5] = 0.0;
+      }
     }
     for (int o = lane; o < M; o += WAVE) {  // largest sample displacement per obstacle (SampledObstacles' whole-obstacle test)
       double r2 = 0.0;
@@ -432,7 +475,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   {  // largest step between adjacent path samples in y: closest_sample's second window (cilqr_device.hpp)
     double m = 0.0;
     for (int q = lane; q + 1 < S; q += WAVE) {
-      const double d = fabs(samp[2 * (q + 1) + 1] - samp[2 * q + 1]);
+      const double d = fabs(samp[q + 1] - samp[q]);
       m = fmax(m, d == d ? d : __builtin_huge_val());
     }
     grid.dmax = readfirstlane_f64(wave_max(m));
@@ -607,12 +650,12 @@ hipError_t launch_pair(const SolveArgs& a, size_t lds, hipStream_t stream) {
 }  // namespace
 
 size_t solve_lds_bytes(int N, int n_samples) {
-  const size_t doubles = 2 * (size_t)n_samples + 2 * (size_t)(N + 1) * XR + 2 * (size_t)2 * N + (size_t)N * REC + (size_t)N * KR;
+  const size_t doubles = (((size_t)n_samples + 1) & ~(size_t)1) + 2 * (size_t)(N + 1) * XR + 2 * (size_t)2 * N + (size_t)N * REC + (size_t)N * KR;
   return doubles * sizeof(double);
 }
 
 size_t solve_sampled_lds_bytes(int n_obs, int n_samples) {
-  return ((size_t)n_obs * n_samples * OFFF + (size_t)n_obs) * sizeof(double);  // offset records + rmax
+  return ((size_t)n_obs * n_samples * OFFF + (size_t)2 * n_obs) * sizeof(double);  // offset records + rmax + constant-shape flags
 }
 size_t solve_sampled_tab_doubles(int n_obs, int N) { return (size_t)n_obs * NOMF * N; }
 
