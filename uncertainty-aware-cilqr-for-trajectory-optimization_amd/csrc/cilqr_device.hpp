@@ -432,7 +432,10 @@ struct Rec {
 // The uncertainty-map term (I/Constraints.cpp:188-201) is NOT added here: the kernels add it to the stored record in a loop of
 // its own (unc_cost_add — after the obstacle terms, i.e. in the reference's order of summation), which keeps its registers out of
 // the obstacle loop's allocation (inlined here it cost the table-streaming configuration a third of its speed).
-template <bool CULL = false, typename ObsAt>
+// PAIRED (with CULL): entries are taken two at a time with four entries' loads in flight — for obstacle tables streamed from
+// global memory, where it is worth 12 % (config 3 materialised: 7.6 → 6.6 ms); where the entries come from LDS the extra live
+// registers cost more than the overlap brings (config 2 +2.4 %, config 3 compact +2 %), so it is off there.
+template <bool CULL = false, bool PAIRED = false, typename ObsAt>
 __device__ __forceinline__ double lin_step(const KParams& kp, double px, double py, double v, double ct, double st, double u0,
                                            double u1, double vn, double cn, double sn, double cx, double cy, int M, ObsAt obs,
                                            Rec& r) {
@@ -452,29 +455,34 @@ __device__ __forceinline__ double lin_step(const KParams& kp, double px, double 
   // carried in the scalar factors (exact: powers of two), not applied to the vector.
   const double svf = -2 * (kp.q2_front * kp.q1_front), smf = 4 * (kp.q2_front * kp.q2_front * kp.q1_front);
   const double svr = -2 * (kp.q2_rear * kp.q1_rear), smr = 4 * (kp.q2_rear * kp.q2_rear * kp.q1_rear);
-  auto add_entry = [&](const ObsEntry& e, double w) {
-    // both circles up to the barrier argument c = 1 - d'Pd (I/Obstacle.cpp:65-73, 86-94)
-    double d0[2], d1[2], g0[2], g1[2], arg[2];
+  struct Prep {  // an entry up to its barrier arguments
+    double g0[2], g1[2], arg[2];
+  };
+  // both circles up to the barrier argument c = 1 - d'Pd (I/Obstacle.cpp:65-73, 86-94)
+  auto prep = [&](const ObsEntry& e, Prep& p) {
 #pragma unroll
     for (int side = 0; side < 2; ++side) {
       const double ex = (side == 0 ? fxp : rxp) - e.ox, ey = (side == 0 ? fyp : ryp) - e.oy;
-      d0[side] = e.co * ex + e.so * ey;
-      d1[side] = e.co * ey - e.so * ex;
-      g0[side] = d0[side] * e.ia2;
-      g1[side] = d1[side] * e.ib2;
-      const double c = 1 - (g0[side] * d0[side] + g1[side] * d1[side]);
-      arg[side] = (side == 0 ? kp.q2_front : kp.q2_rear) * c;
+      const double d0 = e.co * ex + e.so * ey;
+      const double d1 = e.co * ey - e.so * ex;
+      p.g0[side] = d0 * e.ia2;
+      p.g1[side] = d1 * e.ib2;
+      const double c = 1 - (p.g0[side] * d0 + p.g1[side] * d1);
+      p.arg[side] = (side == 0 ? kp.q2_front : kp.q2_rear) * c;
     }
-    if (CULL) {
-      const bool needed = !(arg[0] <= -64.0) || !(arg[1] <= -64.0);
-      if (__builtin_amdgcn_ballot_w64(needed) == 0) return;
-    }
+  };
+  // the wave-wide vote of CULL: false when the entry is negligible at every step of the wavefront
+  auto wanted = [&](const Prep& p) {
+    const bool needed = !(p.arg[0] <= -64.0) || !(p.arg[1] <= -64.0);
+    return __builtin_amdgcn_ballot_w64(needed) != 0;
+  };
+  auto finish = [&](const ObsEntry& e, const Prep& p, double w) {
     double gx = 0.0, gy = 0.0, gxx = 0.0, gxy = 0.0, gyy = 0.0;
 #pragma unroll
     for (int side = 0; side < 2; ++side) {
-      const double h0 = e.co * g0[side] - e.so * g1[side];  // c-dot = -2 (h0, h1)
-      const double h1 = e.so * g0[side] + e.co * g1[side];
-      const double ee = exp_fast(arg[side]);
+      const double h0 = e.co * p.g0[side] - e.so * p.g1[side];  // c-dot = -2 (h0, h1)
+      const double h1 = e.so * p.g0[side] + e.co * p.g1[side];
+      const double ee = exp_fast(p.arg[side]);
       const double sv = (side == 0 ? svf : svr) * ee;
       const double sm = (side == 0 ? smf : smr) * ee;
       gx += sv * h0;
@@ -489,20 +497,66 @@ __device__ __forceinline__ double lin_step(const KParams& kp, double px, double 
     h01 += gxy * w;
     h11 += gyy * w;
   };
-  // two entries in flight, alternating registers: the next entry's loads fly while this one computes.  `obs` returns false
-  // for an entry it has already established to be negligible (SampledObstacles: a whole far obstacle at once).
-  ObsEntry ea, eb;
-  double wa = 0.0, wb = 0.0;
-  bool va = false, vb = false;
-  if (M > 0) va = obs(0, ea, wa);
-  int m = 0;
-  for (; m + 1 < M; m += 2) {
-    vb = obs(m + 1, eb, wb);
-    if (va) add_entry(ea, wa);
-    if (m + 2 < M) va = obs(m + 2, ea, wa);
-    if (vb) add_entry(eb, wb);
+  if (CULL && PAIRED) {
+    // Entries in PAIRS: the geometry of both first — two independent dependency chains that interleave (a lone wavefront issues a
+    // dependent fp64 instruction every 8.5 ticks, an independent one every 5.2) — then one vote each, then the exponentials of
+    // those that matter, in entry order (the sums are formed exactly as one by one).  The next pair's loads are issued between
+    // the geometry and the votes.  `obs` returns false for an entry it has already established to be negligible
+    // (SampledObstacles: a whole far obstacle at once); its stale registers still go through prep, which costs nothing that
+    // matters and keeps the pair free of branches.
+    ObsEntry e0{0, 0, 1, 0, 0, 0}, e1 = e0, e2 = e0, e3 = e0;
+    double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
+    bool v0 = false, v1 = false, v2 = false, v3 = false;
+    if (M > 0) v0 = obs(0, e0, w0);
+    if (M > 1) v1 = obs(1, e1, w1);
+    for (int m = 0; m < M; m += 4) {
+      {
+        Prep pa, pb;
+        const bool any = v0 || v1;  // wave-uniform
+        if (any) { prep(e0, pa); prep(e1, pb); }
+        v2 = m + 2 < M ? obs(m + 2, e2, w2) : false;
+        v3 = m + 3 < M ? obs(m + 3, e3, w3) : false;
+        if (any) {
+          const bool na = v0 && wanted(pa), nb = v1 && wanted(pb);
+          if (na) finish(e0, pa, w0);
+          if (nb) finish(e1, pb, w1);
+        }
+      }
+      if (m + 2 >= M) break;
+      {
+        Prep pa, pb;
+        const bool any = v2 || v3;
+        if (any) { prep(e2, pa); prep(e3, pb); }
+        v0 = m + 4 < M ? obs(m + 4, e0, w0) : false;
+        v1 = m + 5 < M ? obs(m + 5, e1, w1) : false;
+        if (any) {
+          const bool na = v2 && wanted(pa), nb = v3 && wanted(pb);
+          if (na) finish(e2, pa, w2);
+          if (nb) finish(e3, pb, w3);
+        }
+      }
+    }
+  } else {
+    // two entries in flight, alternating registers: the next entry's loads fly while this one computes
+    auto add_entry = [&](const ObsEntry& e, double w) {
+      Prep p;
+      prep(e, p);
+      if (CULL && !wanted(p)) return;
+      finish(e, p, w);
+    };
+    ObsEntry ea, eb;
+    double wa = 0.0, wb = 0.0;
+    bool va = false, vb = false;
+    if (M > 0) va = obs(0, ea, wa);
+    int m = 0;
+    for (; m + 1 < M; m += 2) {
+      vb = obs(m + 1, eb, wb);
+      if (va) add_entry(ea, wa);
+      if (m + 2 < M) va = obs(m + 2, ea, wa);
+      if (vb) add_entry(eb, wb);
+    }
+    if (m < M && va) add_entry(ea, wa);
   }
-  if (m < M && va) add_entry(ea, wa);
 
   // --- control cost (I/Constraints.cpp:110-131)
   const double e1 = exp_fast(kp.q2_acc * (u0 - kp.acc_max));

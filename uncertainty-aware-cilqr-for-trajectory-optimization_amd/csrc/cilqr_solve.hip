@@ -77,7 +77,9 @@ struct TabObstacles {  // obstacle accessor over the [m][t][field] table (LDS or
   }
 };
 
-struct TabSource {  // every obstacle has its own table row
+template <bool STREAMED>
+struct TabSource {  // every obstacle has its own table row; STREAMED: the table lies in global memory (lin_step's PAIRED mode)
+  static constexpr bool kPaired = STREAMED;
   const double* tab;
   const double* wts;
   int N;
@@ -151,6 +153,7 @@ struct SampledObstacles {
   }
 };
 struct SampledSource {
+  static constexpr bool kPaired = false;
   const double* nom;
   const double* off;
   const double* rmax;
@@ -182,7 +185,7 @@ __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int
     const double px = xr[0], py = xr[1];
     const int cs = closest_sample(S, grid, px, py, LdsSamples{samp, grid.xf, grid.dxs});
     Rec c;
-    Jpart += lin_step<true>(kp, px, py, xr[2], xr[4], xr[5], U[2 * t], U[2 * t + 1], xn[2], xn[4], xn[5], fma(grid.dxs, (double)cs, grid.xf),
+    Jpart += lin_step<true, Source::kPaired>(kp, px, py, xr[2], xr[4], xr[5], U[2 * t], U[2 * t + 1], xn[2], xn[4], xn[5], fma(grid.dxs, (double)cs, grid.xf),
                       samp[cs], M, src.at(t), c);
     double* r = rec + t * REC;
     r[0] = c.lx0; r[1] = c.lx1; r[2] = c.lx2; r[3] = c.l00; r[4] = c.l01; r[5] = c.l11;
@@ -520,7 +523,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
       const UncArgs* unc = has_unc ? &phase_args().unc : nullptr;  // uniform: a map is set (cilqr_set_uncertainty_map*)
       if (TAB == 2) part = linearize(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, SampledSource{tab, off, rmax, Xc, N, a.n_samples, M, a.samp_w, kpl.ego_front, kpl.ego_rear,
                                                      sqrt(1.0 + 64.0 / kpl.q2_front), sqrt(1.0 + 64.0 / kpl.q2_rear)}, unc, upose, b);
-      else part = linearize(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, TabSource{tab, wts, N, kpl.w_obstacle}, unc, upose, b);
+      else part = linearize(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, TabSource<TAB == 0>{tab, wts, N, kpl.w_obstacle}, unc, upose, b);
       J_new = readfirstlane_f64(wave_sum(part));
     }
     j_valid = true;
