@@ -174,7 +174,8 @@ struct SampledSource {
 };
 
 // Phase L.  Returns this lane's partial of J over its timesteps.  M = number of obstacle entries per step.
-template <typename Source>
+// RECW: doubles per stored record — 16, or 14 in the production kernel, whose Riccati step does not read p and q any more.
+template <int RECW, typename Source>
 __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int lane, const double* samp, int S,
                                             const SampleGrid& grid, const double* X, const double* U, double* rec,
                                             const Source& src, const UncArgs* unc, UncPose upose, int ub) {
@@ -187,15 +188,16 @@ __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int
     Rec c;
     Jpart += lin_step<true, Source::kPaired>(kp, px, py, xr[2], xr[4], xr[5], U[2 * t], U[2 * t + 1], xn[2], xn[4], xn[5], fma(grid.dxs, (double)cs, grid.xf),
                       samp[cs], M, src.at(t), c);
-    double* r = rec + t * REC;
+    double* r = rec + t * RECW;
     r[0] = c.lx0; r[1] = c.lx1; r[2] = c.lx2; r[3] = c.l00; r[4] = c.l01; r[5] = c.l11;
     r[6] = c.lu0; r[7] = c.lu1; r[8] = c.luu0; r[9] = c.luu1;
-    r[10] = c.al; r[11] = c.be; r[12] = c.ga; r[13] = c.de; r[14] = c.p; r[15] = c.q;
+    r[10] = c.al; r[11] = c.be; r[12] = c.ga; r[13] = c.de;
+    if (RECW == REC) { r[14] = c.p; r[15] = c.q; }
   }
   if (unc) {  // uniform: a map is set — its term joins l_x, l_xx after the obstacles' (I/Constraints.cpp:188-201)
     for (int t = lane; t < N; t += WAVE) {
       const double* xr = X + t * XR;
-      double* r = rec + t * REC;
+      double* r = rec + t * RECW;
       double lx0 = r[0], lx1 = r[1], h00 = r[3], h01 = r[4], h11 = r[5];
       unc_cost_add(*unc, upose, ub, xr[0], xr[1], xr[4], xr[5], lx0, lx1, h00, h01, h11);
       r[0] = lx0; r[1] = lx1; r[3] = h00; r[4] = h01; r[5] = h11;
@@ -216,11 +218,13 @@ __device__ __forceinline__ double cost_only(const KParams& kp, int N, int lane, 
   return Jpart;
 }
 
+template <int RECW>
 __device__ __forceinline__ void load_rec(Rec& o, const double* rec, int j) {
-  const double* r = rec + j * REC;
+  const double* r = rec + j * RECW;
   o.lx0 = r[0]; o.lx1 = r[1]; o.lx2 = r[2]; o.l00 = r[3]; o.l01 = r[4]; o.l11 = r[5];
   o.lu0 = r[6]; o.lu1 = r[7]; o.luu0 = r[8]; o.luu1 = r[9];
-  o.al = r[10]; o.be = r[11]; o.ga = r[12]; o.de = r[13]; o.p = r[14]; o.q = r[15];
+  o.al = r[10]; o.be = r[11]; o.ga = r[12]; o.de = r[13];
+  if (RECW == REC) { o.p = r[14]; o.q = r[15]; } else { o.p = 0.0; o.q = 0.0; }
 }
 
 __device__ __forceinline__ void store_gains(double* kK, int j, const Gains& g) {
@@ -237,10 +241,11 @@ __device__ __forceinline__ void store_gains(double* kK, int j, const Gains& g) {
 // GENERAL = true : branching pass; false ⇒ non-finite Q_uu (the reference's backward_pass returns false).
 template <bool GENERAL>
 __device__ __forceinline__ bool riccati(const KParams& kp, int N, const double* rec, double* kK, double lamb_in) {
+  constexpr int RW = GENERAL ? REC : REC - 2;
   double dt = kp.dt, two_wvel = kp.w_vel * 2, lamb = lamb_in;
   CILQR_PIN(dt); CILQR_PIN(two_wvel); CILQR_PIN(lamb);
   Rec ra, rb;
-  load_rec(ra, rec, N - 1);
+  load_rec<RW>(ra, rec, N - 1);
   Value V;
   value_terminal(V, ra, two_wvel);
   unsigned long long suspect = 0;
@@ -248,11 +253,11 @@ __device__ __forceinline__ bool riccati(const KParams& kp, int N, const double* 
   bool ok;
   int j = N - 1;
   for (; j >= 1; j -= 2) {
-    load_rec(rb, rec, j - 1);
+    load_rec<RW>(rb, rec, j - 1);
     riccati_step<!GENERAL>(ra, V, dt, two_wvel, lamb, g, ok);
     if (GENERAL) { if (!ok) return false; } else suspect |= __builtin_amdgcn_ballot_w64(!ok);
     store_gains(kK, j, g);
-    load_rec(ra, rec, j >= 2 ? j - 2 : 0);
+    load_rec<RW>(ra, rec, j >= 2 ? j - 2 : 0);
     riccati_step<!GENERAL>(rb, V, dt, two_wvel, lamb, g, ok);
     if (GENERAL) { if (!ok) return false; } else suspect |= __builtin_amdgcn_ballot_w64(!ok);
     store_gains(kK, j - 1, g);
@@ -378,13 +383,20 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   if (b >= a.B) return;
   if (GENERAL && a.redo[b] == 0) return;
 
+  // The production kernel runs the forward pass IN PLACE unless CILQR_FLAG_FAITHFUL_ITERS is set: with the early exit a forward
+  // pass is only ever run for an accepted iteration, so its result always replaces the trajectory it started from, and the pass
+  // reads a step's old state, control and gains one step before it overwrites them (forward_fast).  No candidate buffers, and
+  // records of 14 doubles (its Riccati step forms the products with row 0 of fu from those with row 2 of fx): 4 KB less LDS per
+  // solve at N = 50 — which is what lets a CU hold six workgroups of the sampled-obstacle configuration instead of five.
+  constexpr int RECW = GENERAL ? REC : REC - 2;
+  const bool twin = GENERAL || (a.flags & CILQR_FLAG_FAITHFUL_ITERS) != 0;
   double* samp = lds;
   double* Xa = samp + ((S + 1) & ~1);  // (even count: the records behind stay 16-byte aligned)
-  double* Xb = Xa + (N + 1) * XR;
+  double* Xb = twin ? Xa + (N + 1) * XR : Xa;
   double* Ua = Xb + (N + 1) * XR;
-  double* Ub = Ua + 2 * N;
+  double* Ub = twin ? Ua + 2 * N : Ua;
   double* rec = Ub + 2 * N;
-  double* kK = rec + N * REC;
+  double* kK = rec + N * RECW;
   double* tab = TAB == 1 ? kK + N * KR : a.obs_tab + (size_t)b * M * (TAB == 2 ? NOMF : TABF) * N;
   double* off = kK + N * KR;  // TAB == 2: offset records [o][s][OFFF], then rmax[o]
   double* rmax = off + (size_t)M * a.n_samples * OFFF;
@@ -521,9 +533,9 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
       double part;
       const KParams kpl = phase_params();  // phase-local read of the parameter block (cilqr_device.hpp)
       const UncArgs* unc = has_unc ? &phase_args().unc : nullptr;  // uniform: a map is set (cilqr_set_uncertainty_map*)
-      if (TAB == 2) part = linearize(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, SampledSource{tab, off, rmax, Xc, N, a.n_samples, M, a.samp_w, kpl.ego_front, kpl.ego_rear,
+      if (TAB == 2) part = linearize<RECW>(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, SampledSource{tab, off, rmax, Xc, N, a.n_samples, M, a.samp_w, kpl.ego_front, kpl.ego_rear,
                                                      sqrt(1.0 + 64.0 / kpl.q2_front), sqrt(1.0 + 64.0 / kpl.q2_rear)}, unc, upose, b);
-      else part = linearize(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, TabSource<TAB == 0>{tab, wts, N, kpl.w_obstacle}, unc, upose, b);
+      else part = linearize<RECW>(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, TabSource<TAB == 0>{tab, wts, N, kpl.w_obstacle}, unc, upose, b);
       J_new = readfirstlane_f64(wave_sum(part));
     }
     j_valid = true;
@@ -631,31 +643,40 @@ __global__ void unc_cost_kernel(UncArgs u, int n, const double* states, double* 
   mx[3 * i] = h00 * inv; mx[3 * i + 1] = h01 * inv; mx[3 * i + 2] = h11 * inv;
 }
 
+// Bytes of the per-solve arrays: `compact` = the production kernel without CILQR_FLAG_FAITHFUL_ITERS (forward pass in place,
+// 14-double records); otherwise candidate buffers and 16-double records.
+size_t core_lds_bytes(int N, int n_samples, bool compact) {
+  const size_t traj = (size_t)(N + 1) * XR + (size_t)2 * N;
+  const size_t doubles = (((size_t)n_samples + 1) & ~(size_t)1) + (compact ? 1 : 2) * traj + (size_t)N * (compact ? REC - 2 : REC) + (size_t)N * KR;
+  return doubles * sizeof(double);
+}
+
+// `extra`: bytes behind the per-solve arrays (obstacle table or sample records), the same for both kernels of the pair.
 template <bool DIAG, int TAB, bool UNC>
-hipError_t launch_pair_unc(const SolveArgs& a, size_t lds, hipStream_t stream) {
-  if (lds > 64 * 1024) {  // long horizons: opt in to more than the default 64 KiB of dynamic LDS (the CU has 160 KiB)
+hipError_t launch_pair_unc(const SolveArgs& a, size_t extra, hipStream_t stream) {
+  const bool faithful = (a.flags & CILQR_FLAG_FAITHFUL_ITERS) != 0;
+  const size_t lds_fast = core_lds_bytes(a.N, a.kp.n_samples, !faithful) + extra;
+  const size_t lds_general = core_lds_bytes(a.N, a.kp.n_samples, false) + extra;
+  if (lds_general > 64 * 1024) {  // long horizons: opt in to more than the default 64 KiB of dynamic LDS (the CU has 160 KiB)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cilqr_solve_kernel<DIAG, TAB, false, UNC>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_general);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cilqr_solve_kernel<DIAG, TAB, true, UNC>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_general);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, TAB, false, UNC>), dim3(a.B), dim3(WAVE), lds, stream, a);
-  hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, TAB, true, UNC>), dim3(a.B), dim3(WAVE), lds, stream, a);
+  hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, TAB, false, UNC>), dim3(a.B), dim3(WAVE), lds_fast, stream, a);
+  hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, TAB, true, UNC>), dim3(a.B), dim3(WAVE), lds_general, stream, a);
   return hipGetLastError();
 }
 template <bool DIAG, int TAB>
-hipError_t launch_pair(const SolveArgs& a, size_t lds, hipStream_t stream) {
-  return a.unc.layer ? launch_pair_unc<DIAG, TAB, true>(a, lds, stream) : launch_pair_unc<DIAG, TAB, false>(a, lds, stream);
+hipError_t launch_pair(const SolveArgs& a, size_t extra, hipStream_t stream) {
+  return a.unc.layer ? launch_pair_unc<DIAG, TAB, true>(a, extra, stream) : launch_pair_unc<DIAG, TAB, false>(a, extra, stream);
 }
 
 }  // namespace
 
-size_t solve_lds_bytes(int N, int n_samples) {
-  const size_t doubles = (((size_t)n_samples + 1) & ~(size_t)1) + 2 * (size_t)(N + 1) * XR + 2 * (size_t)2 * N + (size_t)N * REC + (size_t)N * KR;
-  return doubles * sizeof(double);
-}
+size_t solve_lds_bytes(int N, int n_samples) { return core_lds_bytes(N, n_samples, false); }  // the larger of the two layouts
 
 size_t solve_sampled_lds_bytes(int n_obs, int n_samples) {
   return ((size_t)n_obs * n_samples * OFFF + (size_t)2 * n_obs) * sizeof(double);  // offset records + rmax + constant-shape flags
@@ -676,19 +697,19 @@ hipError_t launch_quu_inverse(int n, const double* q, const double* lamb, double
 
 hipError_t launch_solve_wave(const SolveArgs& a, hipStream_t stream) {
   if (a.B <= 0) return hipSuccess;
-  size_t lds = solve_lds_bytes(a.N, a.kp.n_samples);
+  const size_t lds = solve_lds_bytes(a.N, a.kp.n_samples);  // the larger layout: limits and the table decision hold for both kernels
   // Keep the obstacle table in LDS while a workgroup stays within 32 KiB (≥ 5 solves resident per CU of 160 KiB).
   const size_t tab_bytes = (size_t)a.M * TABF * a.N * sizeof(double);
   const bool tab_lds = a.n_samples == 0 && a.M > 0 && lds + tab_bytes <= 32 * 1024;
-  if (tab_lds) lds += tab_bytes;
   if (a.n_samples > 0) {  // sampled obstacles: offset records in LDS, nominal records in the global workspace
-    lds += solve_sampled_lds_bytes(a.M, a.n_samples);
-    if (lds > SOLVE_LDS_MAX) return hipErrorInvalidValue;  // checked by the caller
-    return a.diag ? launch_pair<true, 2>(a, lds, stream) : launch_pair<false, 2>(a, lds, stream);
+    const size_t extra = solve_sampled_lds_bytes(a.M, a.n_samples);
+    if (lds + extra > SOLVE_LDS_MAX) return hipErrorInvalidValue;  // checked by the caller
+    return a.diag ? launch_pair<true, 2>(a, extra, stream) : launch_pair<false, 2>(a, extra, stream);
   }
   if (lds > SOLVE_LDS_MAX) return hipErrorInvalidValue;  // checked by the caller
-  if (a.diag) return tab_lds ? launch_pair<true, 1>(a, lds, stream) : launch_pair<true, 0>(a, lds, stream);
-  return tab_lds ? launch_pair<false, 1>(a, lds, stream) : launch_pair<false, 0>(a, lds, stream);
+  const size_t extra = tab_lds ? tab_bytes : 0;
+  if (a.diag) return tab_lds ? launch_pair<true, 1>(a, extra, stream) : launch_pair<true, 0>(a, extra, stream);
+  return tab_lds ? launch_pair<false, 1>(a, extra, stream) : launch_pair<false, 0>(a, extra, stream);
 }
 
 }  // namespace cilqr
