@@ -55,7 +55,7 @@ extern "C" {
 #define CILQR_NX 4
 #define CILQR_NU 2
 #define CILQR_POLY_COEFFS 6   /* poly_order + 1, I/Parameters.cpp:7 */
-#define CILQR_MAX_HORIZON 384  /* per-solve arrays of the LDS-resident family at the default sample count: 128 KiB of 160 */
+#define CILQR_MAX_HORIZON 384  /* per-solve arrays of the LDS-resident family at the default sample count: 98 KiB of 160 */
 #define CILQR_ABI_VERSION 2
 #define CILQR_COMM_ID_BYTES 128 /* an RCCL ncclUniqueId, carried opaquely */
 

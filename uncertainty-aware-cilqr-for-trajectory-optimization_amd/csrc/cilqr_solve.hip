@@ -15,7 +15,7 @@
 //   X a/b [(N+1)][6]    state records {x, y, v, theta, cos theta, sin theta}, double-buffered (X / X_new)
 //   U a/b [N][2]        controls, double-buffered (U / U_new)
 //   rec   [N][16]       per-step linearisation {l_x(3), l_xx(3), l_u(2), l_uu(2), A/B entries(6)}
-//   kK    [N][10]       feed-forward k and feedback K of the backward pass
+//   kK                  feed-forward k and feedback K of the backward pass: stored over the record of their step
 //   tab   [M][N][6]     obstacle table (when it fits; else the same layout in a global workspace)
 // Phases per iteration:
 //   L  lanes = timesteps: closest path sample, tracking + obstacle + control barrier derivatives, A/B entries,
@@ -227,9 +227,13 @@ __device__ __forceinline__ void load_rec(Rec& o, const double* rec, int j) {
   if (RECW == REC) { o.p = r[14]; o.q = r[15]; } else { o.p = 0.0; o.q = 0.0; }
 }
 
+// The gains of step j are stored over the first 10 doubles of step j's linearisation record — it has just been read for the
+// last time (the recursion holds it in registers) — so `kK` is the record array itself and KS its record width: no gain array
+// of its own in LDS (4 KB at N = 50).
+template <int KS>
 __device__ __forceinline__ void store_gains(double* kK, int j, const Gains& g) {
   if (threadIdx.x == 0) {  // every lane holds the same values; one lane stores
-    double* o = kK + j * KR;
+    double* o = kK + j * KS;
 #pragma unroll
     for (int i = 0; i < KR; ++i) o[i] = g.g[i];
   }
@@ -256,25 +260,26 @@ __device__ __forceinline__ bool riccati(const KParams& kp, int N, const double* 
     load_rec<RW>(rb, rec, j - 1);
     riccati_step<!GENERAL>(ra, V, dt, two_wvel, lamb, g, ok);
     if (GENERAL) { if (!ok) return false; } else suspect |= __builtin_amdgcn_ballot_w64(!ok);
-    store_gains(kK, j, g);
+    store_gains<RW>(kK, j, g);
     load_rec<RW>(ra, rec, j >= 2 ? j - 2 : 0);
     riccati_step<!GENERAL>(rb, V, dt, two_wvel, lamb, g, ok);
     if (GENERAL) { if (!ok) return false; } else suspect |= __builtin_amdgcn_ballot_w64(!ok);
-    store_gains(kK, j - 1, g);
+    store_gains<RW>(kK, j - 1, g);
   }
   if (j == 0) {
     riccati_step<!GENERAL>(ra, V, dt, two_wvel, lamb, g, ok);
     if (GENERAL) { if (!ok) return false; } else suspect |= __builtin_amdgcn_ballot_w64(!ok);
-    store_gains(kK, 0, g);
+    store_gains<RW>(kK, 0, g);
   }
   return suspect == 0;
 }
 
+template <int KS>
 __device__ __forceinline__ void load_fwd(FwdIn& o, const double* X, const double* U, const double* kK, int i) {
   const double* xo = X + i * XR;
   o.x = xo[0]; o.y = xo[1]; o.v = xo[2]; o.th = xo[3];
   o.u0 = U[2 * i]; o.u1 = U[2 * i + 1];
-  const double* g = kK + i * KR;
+  const double* g = kK + i * KS;
 #pragma unroll
   for (int k = 0; k < KR; ++k) o.g[k] = g[k];
 }
@@ -293,6 +298,7 @@ __device__ __forceinline__ void fwd_step_store(const FwdConst& k, const FwdIn& c
 // step i+1 (old state, old control, gains) are read while step i computes (two steps per trip, no register copies).
 // Returns false if a step turned the heading by more than MAX_TURN (rotate_heading, cilqr_device.hpp): the results are then
 // not to be used and the solve is handed to the GENERAL kernel.
+template <int KS>
 __device__ __forceinline__ bool forward_fast(const KParams& kp, int N, const double* X, const double* U, const double* kK,
                                              double* Xn, double* Un) {
   FwdConst k;
@@ -302,12 +308,12 @@ __device__ __forceinline__ bool forward_fast(const KParams& kp, int N, const dou
   if (threadIdx.x == 0) store_state(Xn, 0, s);
   double max_turn = 0.0;  // (the first heading was checked by the rollout)
   FwdIn fa, fb;
-  load_fwd(fa, X, U, kK, 0);
+  load_fwd<KS>(fa, X, U, kK, 0);
   int i = 0;
   for (; i + 1 < N; i += 2) {
-    load_fwd(fb, X, U, kK, i + 1);
+    load_fwd<KS>(fb, X, U, kK, i + 1);
     fwd_step_store(k, fa, s, max_turn, Un + 2 * i, Xn + (i + 1) * XR);
-    load_fwd(fa, X, U, kK, i + 2 < N ? i + 2 : i + 1);
+    load_fwd<KS>(fa, X, U, kK, i + 2 < N ? i + 2 : i + 1);
     fwd_step_store(k, fb, s, max_turn, Un + 2 * (i + 1), Xn + (i + 2) * XR);
   }
   if (i < N) fwd_step_store(k, fa, s, max_turn, Un + 2 * i, Xn + (i + 1) * XR);
@@ -322,7 +328,7 @@ __device__ __forceinline__ void forward_general(const KParams& kp, int N, const 
   if (threadIdx.x == 0) store_state(Xn, 0, s);
   for (int i = 0; i < N; ++i) {
     const double* xo = X + i * XR;
-    const double* g = kK + i * KR;
+    const double* g = kK + i * REC;  // the GENERAL kernel's records are 16 doubles wide
     const double d0 = s.x - xo[0], d1 = s.y - xo[1], d2 = s.v - xo[2], d3 = s.th - xo[3];
     const double u0 = fma(g[5], d3, fma(g[4], d2, fma(g[3], d1, fma(g[2], d0, U[2 * i] + g[0]))));
     const double u1 = fma(g[9], d3, fma(g[8], d2, fma(g[7], d1, fma(g[6], d0, U[2 * i + 1] + g[1]))));
@@ -396,9 +402,9 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   double* Ua = Xb + (N + 1) * XR;
   double* Ub = twin ? Ua + 2 * N : Ua;
   double* rec = Ub + 2 * N;
-  double* kK = rec + N * RECW;
-  double* tab = TAB == 1 ? kK + N * KR : a.obs_tab + (size_t)b * M * (TAB == 2 ? NOMF : TABF) * N;
-  double* off = kK + N * KR;  // TAB == 2: offset records [o][s][OFFF], then rmax[o]
+  double* kK = rec;  // the gains overlay the records (store_gains)
+  double* tab = TAB == 1 ? rec + N * RECW : a.obs_tab + (size_t)b * M * (TAB == 2 ? NOMF : TABF) * N;
+  double* off = rec + N * RECW;  // TAB == 2: offset records [o][s][OFFF], then rmax[o]
   double* rmax = off + (size_t)M * a.n_samples * OFFF;
 
   // ---- prologue -------------------------------------------------------------------------------------------
@@ -568,7 +574,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
     if (DIAG) ++n_R;
     if (GENERAL) {
       forward_general(kp, N, Xc, Uc, kK, Xn, Un);
-    } else if (!forward_fast(KParams(phase_params()), N, Xc, Uc, kK, Xn, Un)) {
+    } else if (!forward_fast<RECW>(KParams(phase_params()), N, Xc, Uc, kK, Xn, Un)) {
       handover = true;
       break;
     }
@@ -647,7 +653,7 @@ __global__ void unc_cost_kernel(UncArgs u, int n, const double* states, double* 
 // 14-double records); otherwise candidate buffers and 16-double records.
 size_t core_lds_bytes(int N, int n_samples, bool compact) {
   const size_t traj = (size_t)(N + 1) * XR + (size_t)2 * N;
-  const size_t doubles = (((size_t)n_samples + 1) & ~(size_t)1) + (compact ? 1 : 2) * traj + (size_t)N * (compact ? REC - 2 : REC) + (size_t)N * KR;
+  const size_t doubles = (((size_t)n_samples + 1) & ~(size_t)1) + (compact ? 1 : 2) * traj + (size_t)N * (compact ? REC - 2 : REC);  // gains overlay the records
   return doubles * sizeof(double);
 }
 
