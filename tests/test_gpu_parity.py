@@ -333,7 +333,7 @@ def test_quu_inverse_branches_vs_reference_eigensolver(cilqr, solver):
 # ------------------------------------------------------------------------------------------------ grouped kernel family
 @pytest.mark.parametrize("G", [1, 2, 4, 8, 16, 32])
 def test_grouped_kernels_match_oracle(cilqr, oracle, G):
-    """The G-lanes-per-solve kernel family (large batches; chosen automatically above B = 1280) forced onto small batches
+    """The G-lanes-per-solve kernel family (large batches; chosen automatically above one solve per SIMD, B > 1024) forced onto small batches
     through the CILQR_FORCE_G test hook: same parity bar as the wavefront-per-solve family, ragged batch sizes included."""
     import os
     from cilqr_amd import scenes
@@ -378,7 +378,7 @@ def test_grouped_kernels_match_oracle(cilqr, oracle, G):
 
 
 def test_automatic_family_choice_large_batch(cilqr, oracle):
-    """B = 4096 > 1280 takes the grouped family automatically (G = 16); a 256-solve sample is checked against the oracle."""
+    """B = 4096 > 1024 takes the grouped family automatically (G = 16); a 256-solve sample is checked against the oracle."""
     from cilqr_amd import scenes
     p = cilqr.default_params(50)
     sc = scenes.make_static(4096, 50, 4, p, 401)

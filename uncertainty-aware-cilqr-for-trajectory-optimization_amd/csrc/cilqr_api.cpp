@@ -148,6 +148,7 @@ int cilqr_create(const cilqr_params* p, int max_batch, int max_horizon, int max_
   h->params = *p;
   derive(*p, h->kp);
   h->device = device;
+  h->simds = prop.multiProcessorCount > 0 ? prop.multiProcessorCount * 4 : 1024;
   h->max_batch = max_batch; h->max_horizon = max_horizon; h->max_obstacles = max_obstacles;
   if (const char* fg = getenv("CILQR_FORCE_G")) h->force_g = atoi(fg);
   const size_t B = max_batch, N = max_horizon, M = max_obstacles;
@@ -359,17 +360,18 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
   a.B = B; a.N = N; a.M = M; a.flags = flags;
   a.kp = h->kp;
   HIP_TRY(hipSetDevice(h->device));
-  // Kernel family by batch size: up to ≈1.25 solves per SIMD one wavefront per solve (LDS-resident, 0.79 ms
-  // for 1024 solves of config 2 and growing with the second wavefront per SIMD); above, G lanes per solve with G the power of
-  // two nearest below 65536/B (at most 32), i.e. about one wavefront per SIMD of the 1024 (1.0 ms up to B = 2048).
+  // Kernel family by batch size: up to one solve per SIMD (1024 on an MI355X) one wavefront per solve,
+  // LDS-resident — 0.69 ms for 1024 solves of config 2; a second wavefront on a SIMD already slows that SIMD's two solves to
+  // 0.98 ms (measured at B = 1280), more than the grouped family needs for any B up to 2048 (0.82-0.83 ms).  Above, G lanes per
+  // solve with G the power of two nearest below 64·SIMDs/B (at most 32), i.e. about one wavefront per SIMD.
   int G = 64;
   if (h->force_g == 1 || h->force_g == 2 || h->force_g == 4 || h->force_g == 8 || h->force_g == 16 || h->force_g == 32 || h->force_g == 64) {
     G = h->force_g;
-  } else if (B > 1280 && M <= 32) {
+  } else if (B > h->simds && M <= 32) {
     // (with hundreds of obstacle entries per step the solve is a stream over its obstacle table: the wavefront-per-solve
     // family reads it as whole 400-640 B rows per instruction and measures ≈2x faster there — BASELINE config 3)
     G = 32;
-    while (G > 1 && (long)G * B > 65536) G >>= 1;
+    while (G > 1 && (long)G * B > 64L * h->simds) G >>= 1;
   }
   if (G == 64 && cilqr::solve_lds_bytes(N, h->kp.n_samples) > cilqr::SOLVE_LDS_MAX)
     return fail(CILQR_ERR_UNSUPPORTED, "cilqr_solve_batch: horizon %d needs %zu bytes of LDS per solve (limit %zu)", N,

@@ -51,6 +51,7 @@ struct cilqr_handle {
   cilqr_params params;
   cilqr::KParams kp;
   int device;
+  int simds;         // SIMDs of the device (4 per CU): 1024 on an MI355X
   int max_batch, max_horizon, max_obstacles;
   hipStream_t stream;
   // host-buffer entry points (cilqr_host_io.cpp): device arena and pinned staging sized at create, the call in flight

@@ -1,5 +1,5 @@
 // cilqr_solve.hip — batched constrained-iLQR solve for gfx950 (MI355X), ONE WAVEFRONT PER SOLVE, LDS-resident.
-// This is the kernel family for batches up to about one solve per SIMD (B ≤ 1280 on the 1024 SIMDs of an MI355X, e.g.
+// This is the kernel family for batches up to about one solve per SIMD (B ≤ 1024 on the 1024 SIMDs of an MI355X, e.g.
 // BASELINE config 2); larger batches go to the G-lanes-per-solve family in cilqr_solve_groups.hip (launch_solve picks).
 //
 // Hot path of the reference planner: iLQR::get_optimal_control_seq (I/iLQR.cpp:201-245) with everything it
