@@ -31,9 +31,9 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (cannot be collected inside this process): FETCH_SIZE
 # doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950, plus WRITE_SIZE.  Keyed by (workload, batch).
-PMC_TRAFFIC_BYTES = {("c2", 1024): 2 * 5639.07e3 + 2592e3,      # profiles/r02_solver_summary.md
-                     ("c3", 4096): 2 * 230146e3 + 112932e3,     # compact sampled form (materialised: ≈ 23 GB)
-                     ("c5", 8192): 2 * 1.70555e9 + 1.83323e9,   # the global workspace of the grouped family (r01: 8.42 GB)
+PMC_TRAFFIC_BYTES = {("c2", 1024): 2 * 5640.64e3 + 2592e3,      # profiles/r02_solver_summary.md
+                     ("c3", 4096): 2 * 332987e3 + 114197e3,     # compact sampled form (materialised: ≈ 23 GB)
+                     ("c5", 8192): 2 * 1.70435e9 + 1.83323e9,   # the global workspace of the grouped family (r01: 8.42 GB)
                      # profiles/r01_wide_rows_summary.md (KB per dispatch): the 1024^2 destination reads a 512^2 patch of the source
                      ("warp", 1024): 2 * 598.438e3 + 4096e3,
                      ("occ", 8192): 2 * 131103e3 + 65536e3}
