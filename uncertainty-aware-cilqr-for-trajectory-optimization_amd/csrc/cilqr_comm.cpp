@@ -90,6 +90,10 @@ int cilqr_argmin_global_device(cilqr_handle* h, void* stream, int B, const doubl
   if (!h || !out_pair || B < 0 || (B > 0 && !J) || index_offset < 0) return fail(CILQR_ERR_ARG, "cilqr_argmin_global_device: bad argument");
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
+  if (!h->comm && B > 0) {  // a lone rank: the local pick with its offset, one launch
+    HIP_TRY(cilqr::launch_argmin(J, B, out_pair, nullptr, 0.0, s, (double)index_offset));
+    return CILQR_OK;
+  }
   if (B > 0) {
     HIP_TRY(cilqr::launch_argmin(J, B, nullptr, h->d_triple, (double)index_offset, s));
   } else {  // a rank without scenes takes part in the exchange with "no finite cost"

@@ -93,7 +93,8 @@ hipError_t launch_local_plan(const LocalPlanArgs& a, hipStream_t stream);
 size_t local_plan_lds_bytes(int n_wpts, int cols);
 
 // Min-cost selection (cilqr_select.hip).  out_pair {J_min, index} and/or out_triple {J_min, index, offset} (either may be null).
-hipError_t launch_argmin(const double* J, int B, double* out_pair, double* out_triple, double offset, hipStream_t stream);
+hipError_t launch_argmin(const double* J, int B, double* out_pair, double* out_triple, double offset, hipStream_t stream,
+                         double pair_offset = 0.0);
 hipError_t launch_select(const double* triples, int n_ranks, double* out_pair, hipStream_t stream);
 
 struct WarpArgs {

@@ -17,7 +17,9 @@ __device__ __forceinline__ void amin_merge(double& j0, long long& i0, double j1,
   if (j1 < j0 || (j1 == j0 && i1 < i0)) { j0 = j1; i0 = i1; }
 }
 
-__global__ __launch_bounds__(AM_THREADS) void argmin_kernel(const double* J, int B, double* out_pair, double* out_triple, double offset) {
+// pair_offset: added to the index written to out_pair (a lone rank's global index without the gather and select steps).
+__global__ __launch_bounds__(AM_THREADS) void argmin_kernel(const double* J, int B, double* out_pair, double* out_triple, double offset,
+                                                            double pair_offset) {
   __shared__ double sj[AM_THREADS / 64];
   __shared__ long long si[AM_THREADS / 64];
   constexpr long long NONE = 0x7fffffffffffffffll;
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(AM_THREADS) void argmin_kernel(const double* J, int
   if (threadIdx.x == 0) {
     for (int w = 1; w < AM_THREADS / 64; ++w) amin_merge(bj, bi, sj[w], si[w]);
     const double idx = (bi == NONE) ? -1.0 : (double)bi;
-    if (out_pair) { out_pair[0] = bj; out_pair[1] = idx; }
+    if (out_pair) { out_pair[0] = bj; out_pair[1] = idx < 0.0 ? idx : idx + pair_offset; }
     if (out_triple) { out_triple[0] = bj; out_triple[1] = idx; out_triple[2] = offset; }
   }
 }
@@ -61,8 +63,9 @@ __global__ __launch_bounds__(64) void select_kernel(const double* triples, int n
 
 }  // namespace
 
-hipError_t launch_argmin(const double* J, int B, double* out_pair, double* out_triple, double offset, hipStream_t stream) {
-  hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(AM_THREADS), 0, stream, J, B, out_pair, out_triple, offset);
+hipError_t launch_argmin(const double* J, int B, double* out_pair, double* out_triple, double offset, hipStream_t stream,
+                         double pair_offset) {
+  hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(AM_THREADS), 0, stream, J, B, out_pair, out_triple, offset, pair_offset);
   return hipGetLastError();
 }
 
