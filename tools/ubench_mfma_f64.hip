@@ -26,6 +26,7 @@ __global__ __launch_bounds__(64) void order(const double* a, const double* b, co
 
 // (3) time: 256 x 16 instructions, one wavefront per SIMD.  KIND 0: result feeds C; 1: result feeds A; 2: result feeds B;
 // 3: four independent accumulators; 4: result -> one v_fma_f64 -> A of the next (the VALU round trip of a real chain).
+#define V3 asm volatile("v_fma_f64 %0, %3, %4, %0\n v_fma_f64 %1, %3, %4, %1\n v_fma_f64 %2, %3, %4, %2" : "+v"(y0), "+v"(y1), "+v"(y2) : "v"(y3), "v"(y4));
 #define R4(x) x x x x
 #define R16(x) R4(x) R4(x) R4(x) R4(x)
 template <int KIND>
@@ -33,6 +34,7 @@ __global__ __launch_bounds__(64) void chain(double* out, unsigned long long* cyc
   const int l = threadIdx.x;
   double a = (l % 5 == 0) ? 1.0 : 0.0, b = (l % 5 == 0) ? 1.0 : 0.0, c = s * l;  // identity-like operands keep values bounded
   double c1 = c + 1, c2 = c + 2, c3 = c + 3;
+  double y0 = s, y1 = s + 1, y2 = s + 2, y3 = 0.5, y4 = 0.25;
   const unsigned long long t0 = __builtin_readcyclecounter();
   for (int i = 0; i < 256; ++i) {
     if (KIND == 0) { R16(c = MFMA(a, b, c);) }
@@ -40,9 +42,15 @@ __global__ __launch_bounds__(64) void chain(double* out, unsigned long long* cyc
     if (KIND == 2) { R16(b = MFMA(a, b, 0.0);) }
     if (KIND == 3) { R4(c = MFMA(a, b, c); c1 = MFMA(a, b, c1); c2 = MFMA(a, b, c2); c3 = MFMA(a, b, c3);) }
     if (KIND == 4) { R16(a = fma(MFMA(a, b, 0.0), s, 0.0);) }
+    // 5: independent matrix instructions, each with three independent v_fma_f64 beside it — does vector work issue under the
+    //    16 ticks a matrix instruction holds its pipe?  6: the same around a C-dependent chain.
+    if (KIND == 5) { R4(c = MFMA(a, b, c); V3 c1 = MFMA(a, b, c1); V3 c2 = MFMA(a, b, c2); V3 c3 = MFMA(a, b, c3); V3) }
+    if (KIND == 6) { R16(c = MFMA(a, b, c); V3) }
+    // 7: six independent v_fma_f64 beside each independent matrix instruction
+    if (KIND == 7) { R4(c = MFMA(a, b, c); V3 V3 c1 = MFMA(a, b, c1); V3 V3 c2 = MFMA(a, b, c2); V3 V3 c3 = MFMA(a, b, c3); V3 V3) }
   }
   const unsigned long long t1 = __builtin_readcyclecounter();
-  out[l + 64 * blockIdx.x] = a + b + c + c1 + c2 + c3;
+  out[l + 64 * blockIdx.x] = a + b + c + c1 + c2 + c3 + y0 + y1 + y2;
   if (l == 0) cyc[blockIdx.x] = t1 - t0;
 }
 template <int KIND> void run(const char* name, int per) {
@@ -109,5 +117,8 @@ int main() {
   run<2>("result -> B of the next", 0);
   run<3>("four independent accumulators", 0);
   run<4>("result -> v_fma_f64 -> A of the next", 1);
+  run<5>("independent, 3 independent v_fma_f64 beside each", 0);
+  run<6>("C-dependent, 3 independent v_fma_f64 beside each", 0);
+  run<7>("independent, 6 independent v_fma_f64 beside each", 0);
   return 0;
 }

@@ -174,7 +174,7 @@ struct SampledSource {
 };
 
 // Phase L.  Returns this lane's partial of J over its timesteps.  M = number of obstacle entries per step.
-// RECW: doubles per stored record — 16, or 14 in the production kernel, whose Riccati step does not read p and q any more.
+// RECW: doubles per stored record.
 template <int RECW, typename Source>
 __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int lane, const double* samp, int S,
                                             const SampleGrid& grid, const double* X, const double* U, double* rec,
@@ -245,7 +245,7 @@ __device__ __forceinline__ void store_gains(double* kK, int j, const Gains& g) {
 // GENERAL = true : branching pass; false ⇒ non-finite Q_uu (the reference's backward_pass returns false).
 template <bool GENERAL>
 __device__ __forceinline__ bool riccati(const KParams& kp, int N, const double* rec, double* kK, double lamb_in) {
-  constexpr int RW = GENERAL ? REC : REC - 2;
+  constexpr int RW = REC;
   double dt = kp.dt, two_wvel = kp.w_vel * 2, lamb = lamb_in;
   CILQR_PIN(dt); CILQR_PIN(two_wvel); CILQR_PIN(lamb);
   Rec ra, rb;
@@ -277,26 +277,33 @@ __device__ __forceinline__ bool riccati(const KParams& kp, int N, const double* 
 // ---- Phase R on the matrix cores (production kernel) --------------------------------------------------------------------------
 // The recursion is a chain of 4×4 fp64 matrix products, which `riccati` above evaluates entry by entry, every lane computing
 // every entry (≈ 131 fp64 instructions per step on the serial chain).  v_mfma_f64_4x4x4_4b_f64 forms four 4×4×4 products in one
-// instruction; measured on gfx950 (tools/ubench_mfma_f64.hip): a lone wavefront issues one every 16 ticks, 20 / 28 ticks when
-// the result feeds the next one's C / A or B operand, each product a chain of fused multiply-adds.  Its lane map, likewise
-// measured: with a matrix X kept as "entry (r, c) in lane c + 4·blk + 16·r" (blk = 0..3: the instruction's four independent
-// blocks), the instruction computes, per block,   D = Xaᵀ · Xb + Xc   with all four of Xa, Xb, Xc, D in that one layout — a
-// result is the next product's right or (transposed) left operand with no lane movement.  The step below keeps the SAME
-// matrices in all four blocks, so that every result can be any operand of any later product:
-//   PA = V'A            PB = V'B~ + [0 0 V_x 0]                         (B~ = [B 0 0]; V' = V to rounding: V_xx is symmetric)
-//   Q_xx = A'PA + l_xx  UX = B~'PA (rows 0-1: Q_ux)   XU = A'[0 0 V_x 0] + [0 0 l_x 0] (column 2: Q_x)
-//   UU = B~'PB + [l_uu l_u 0]  (rows 0-1: Q_uu | Q_u | 0)                                                  (:149-153)
-//   a, b, d of Q_uu by v_readlane; PSD test, determinant and its reciprocal on all lanes as before;
-//   adj = adjugate of Q_uu + lamb·I laid out by three lane masks;  K = -(adj·UX)/det,  [* k 0] = -(adj·UU)/det   (:155-178)
-//   H = UX + lamb·K  (= -G', the identity of riccati_step<FAST>);  V_xx = Q_xx + H'K;  V_x = column 2 of XU + H'[* k 0]  (:180-181)
-// Ten matrix instructions and ≈ 45 others per step instead of ≈ 162.  The per-step operands are read from the same 14-double
-// records, each lane fetching the entry of its (r, c) — or a constant from a 4-double table {0, 1, dt, 2·w_vel} — through a
-// per-lane LDS address: five ds_read_b64 per step.  Gains leave through the lanes that hold them, into the layout phase F reads.
-// Sums are formed in a different order than in riccati_step (four fused multiply-adds over k per entry, structural zeros
-// included), so results agree with it to rounding, like the other identities of the production kernel; a non-finite or
-// non-PSD Q_uu hands the solve to the GENERAL kernel exactly as before.
+// instruction.  Measured on gfx950 (tools/ubench_mfma_f64.hip): a lone wavefront issues one every 16.2 ticks (20 / 28 when the
+// result feeds the next one's C / A or B operand), each entry a chain of fused multiply-adds, and vector instructions do NOT
+// issue beside it — a matrix instruction costs what three fp64 vector instructions cost, so the count of both is what matters.
+// Its lane map, likewise measured: with a matrix X kept as "entry (r, c) in lane c + 4·blk + 16·r" (blk = 0..3: the
+// instruction's four independent blocks), the instruction computes, per block,   D = Xaᵀ · Xb + Xc   with all four of Xa, Xb, Xc,
+// D in that one layout — a result is the next product's right or (transposed) left operand with no lane movement.
+//
+// Two blocks are used (blocks 2, 3 repeat 0, 1); "[X | Y]" = X in block 0, Y in block 1; B~ = [B 0 0] padded to 4×4:
+//   P  = [V | V]' [A | B~] + [0 | vc]                         = [V'A | V'B~ + vc]          vc = column 2 holds V_x, else 0
+//   Da = [A | A]' P + [l_xx | column 2: l_x]                   = [Q_xx | (Q_xu, Q_x, 0)]                                (:149-151)
+//   Db = [B~ | B~]' P + [0 | (l_uu, l_u, 0)]                   = [Q_ux in rows 0-1 | (Q_uu, Q_u, 0) in rows 0-1]        (:150-153)
+//   a, b, d of Q_uu by v_readlane; PSD test, determinant, reciprocal on all lanes as in riccati_step           (:155-175)
+//   Dk = -(1/det)·[adj | adj]' Db                              = [K in rows 0-1 | (*, k, 0)]      adj = adjugate of Q_uu + lamb·I, laid out by lane masks (:177-178)
+//   H  = Db + lamb·Dk, block 0 copied to block 1               = [Q_ux + lamb·K | same]   (= -G' by the identity of riccati_step<FAST>)
+//   Dv = H' Dk + Da                                            = [V_xx | (*, V_x, 0)]                                   (:180-181)
+//   next V = block 0 of Dv in both blocks; next vc = Dv masked to column 2 of block 1.
+// Five matrix instructions, four DPP moves and ≈ 40 others per step instead of ≈ 162 vector instructions.  V enters the first
+// product transposed: V_xx is symmetric, its two triangles agree to rounding (the reference computes both as well).  The
+// per-step operands come from the same 16-double records, each lane fetching the entry of its (block, r, c) — or a constant
+// from a small table {0, 1, dt, 2·w_vel} — through a per-lane LDS address: five ds_read_b64 per step.  Gains leave through the
+// lanes that hold them, into the layout phase F reads.  Sums are formed in another order than in riccati_step (four fused
+// multiply-adds over k per entry, structural zeros included), so results agree with it to rounding, like the other identities
+// of the production kernel; a non-finite or non-PSD Q_uu hands the solve to the GENERAL kernel exactly as before.
 #define CILQR_MFMA(xa, xb, xc) __builtin_amdgcn_mfma_f64_4x4x4f64(xa, xb, xc, 0, 0, 0)
-constexpr int RCST = 4;  // doubles of the constant table behind the records: {0, 1, dt, 2·w_vel}
+// Constant table behind the records: {0, 1, dt, 2·w_vel} twice, REC doubles apart — a lane that reads a constant keeps its
+// address while the others step through the records, and the two steps of one loop trip are read at immediate offsets 0 and REC.
+constexpr int RCST = REC + 4;
 
 __device__ __forceinline__ double readlane_f64(double v, int l) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -304,89 +311,99 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   hi = __builtin_amdgcn_readlane(hi, l);
   return __hiloint2double(hi, lo);
 }
-
-struct MfmaOperands { double A, B, XX, X, UU; };
-struct MfmaCursor {  // this lane's read position in each operand and its stride (0 for a lane that reads a constant)
-  const double *A, *B, *XX, *X, *UU;
-  int sA, sB, sXX, sX, sUU;
-  __device__ __forceinline__ void next(MfmaOperands& o) {  // read step j, move to step j - 1
-    o.A = *A; o.B = *B; o.XX = *XX; o.X = *X; o.UU = *UU;
-    A -= sA; B -= sB; XX -= sXX; X -= sX; UU -= sUU;
-  }
-};
-
-// slot: record slot (≥ 0) or constant -1 - k of this lane's entry
-__device__ __forceinline__ void mfma_place(const double*& ptr, int& stride, int slot, const double* last_rec, const double* cst, int RW) {
-  ptr = slot >= 0 ? last_rec + slot : cst + (-1 - slot);
-  stride = slot >= 0 ? RW : 0;
+// block 1 (and 3) := block 0 (and 2), rows kept: DPP row_shr:4 under bank mask 0b1010
+__device__ __forceinline__ double odd_blocks_from_even(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x114, 0xF, 0xA, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x114, 0xF, 0xA, false);
+  return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ bool riccati_mfma(const KParams& kp, int N, const double* rec, double* kK, const double* cst, double lamb_in) {
-  constexpr int RW = REC - 2;
+struct MfmaOperands { double AB, AA, BB, Ca, Cb; };
+struct MfmaCursor {  // this lane's read position in each operand (at the LOWER step of a pair) and its stride per pair (0: constant)
+  const double *AB, *AA, *BB, *Ca, *Cb;
+  int sAB, sAA, sBB, sCa, sCb;
+  __device__ __forceinline__ void upper(MfmaOperands& o) const { o.AB = AB[REC]; o.AA = AA[REC]; o.BB = BB[REC]; o.Ca = Ca[REC]; o.Cb = Cb[REC]; }
+  __device__ __forceinline__ void lower(MfmaOperands& o) const { o.AB = AB[0]; o.AA = AA[0]; o.BB = BB[0]; o.Ca = Ca[0]; o.Cb = Cb[0]; }
+  __device__ __forceinline__ void back() { AB -= sAB; AA -= sAA; BB -= sBB; Ca -= sCa; Cb -= sCb; }
+};
+
+// slot: record slot (≥ 0) or constant -1 - k of this lane's entry; `low`: the record below the topmost one
+__device__ __forceinline__ void mfma_place(const double*& ptr, int& stride, int slot, const double* low, const double* cst) {
+  ptr = slot >= 0 ? low + slot : cst + (-1 - slot);
+  stride = slot >= 0 ? 2 * REC : 0;
+}
+
+__device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* kK, const double* cst, double lamb_in) {
   constexpr int C0 = -1, C1 = -2, CDT = -3, CW = -4;
   const int lane = threadIdx.x;
   const int e = ((lane >> 4) << 2) | (lane & 3);  // 4·r + c of this lane's entry
-  // record slots: 0-2 l_x, 3-5 l_xx (00, 01, 11), 6-7 l_u, 8-9 l_uu, 10-13 al, be, ga, de (linearize)
+  const bool odd = (lane & 4) != 0;               // block 1 (or 3)
+  // record slots: 0-2 l_x, 3-5 l_xx (00, 01, 11), 6-7 l_u, 8-9 l_uu, 10-13 al, be, ga, de, 14-15 p, q (linearize)
   const int slotA = e == 0 || e == 5 || e == 10 || e == 15 ? C1 : e == 2 ? 10 : e == 6 ? 11 : e == 3 ? 12 : e == 7 ? 13 : C0;
-  const int slotB = e == 0 ? 10 : e == 4 ? 11 : e == 8 || e == 13 ? CDT : C0;  // (p, q) = (dt/2)·(al, be): scaled below
+  const int slotB = e == 0 ? 14 : e == 4 ? 15 : e == 8 || e == 13 ? CDT : C0;
   const int slotXX = e == 0 ? 3 : e == 1 || e == 4 ? 4 : e == 5 ? 5 : e == 10 ? CW : C0;
   const int slotX = e == 2 ? 0 : e == 6 ? 1 : e == 10 ? 2 : C0;
   const int slotUU = e == 0 ? 8 : e == 5 ? 9 : e == 2 ? 6 : e == 6 ? 7 : C0;
-  const double* last = rec + (N - 1) * RW;
+  const double* low = rec + (N - 2) * REC;  // (N = 1: the record "below" is never read)
   MfmaCursor cur;
-  mfma_place(cur.A, cur.sA, slotA, last, cst, RW);
-  mfma_place(cur.B, cur.sB, slotB, last, cst, RW);
-  mfma_place(cur.XX, cur.sXX, slotXX, last, cst, RW);
-  mfma_place(cur.X, cur.sX, slotX, last, cst, RW);
-  mfma_place(cur.UU, cur.sUU, slotUU, last, cst, RW);
-  double bscale = e == 0 || e == 4 ? 0.5 * kp.dt : 1.0;
+  mfma_place(cur.AB, cur.sAB, odd ? slotB : slotA, low, cst);
+  mfma_place(cur.AA, cur.sAA, slotA, low, cst);
+  mfma_place(cur.BB, cur.sBB, slotB, low, cst);
+  mfma_place(cur.Ca, cur.sCa, odd ? slotX : slotXX, low, cst);
+  mfma_place(cur.Cb, cur.sCb, odd ? slotUU : C0, low, cst);
   double m00 = e == 0 ? 1.0 : 0.0, m01 = e == 1 || e == 4 ? 1.0 : 0.0, m11 = e == 5 ? 1.0 : 0.0;
-  double mcol2 = (lane & 3) == 2 ? 1.0 : 0.0;
+  double mvc = odd && (lane & 3) == 2 ? 1.0 : 0.0;
   double lamb = lamb_in;
-  CILQR_PIN(bscale); CILQR_PIN(m00); CILQR_PIN(m01); CILQR_PIN(m11); CILQR_PIN(mcol2); CILQR_PIN(lamb);
-  // gains: K(0, c) in lanes 0-3, K(1, c) in lanes 16-19 of KK; k(0), k(1) in column 2 of KV — taken from block 1 (lanes 6, 22)
-  const bool from_kv = lane == 6 || lane == 22;
-  const bool stores = from_kv || lane < 4 || (lane >= 16 && lane < 20);
-  double* gp = kK + (N - 1) * RW + (lane == 6 ? 0 : lane == 22 ? 1 : lane < 4 ? 2 + lane : 6 + (lane & 3));
+  CILQR_PIN(m00); CILQR_PIN(m01); CILQR_PIN(m11); CILQR_PIN(mvc); CILQR_PIN(lamb);
+  // gains in Dk: K(0, c) in lanes 0-3, K(1, c) in lanes 16-19 (block 0); k(0), k(1) in lanes 6, 22 (column 2 of block 1)
+  const bool stores = lane == 6 || lane == 22 || lane < 4 || (lane >= 16 && lane < 20);
+  double* gp = kK + (N - 1) * REC + (lane == 6 ? 0 : lane == 22 ? 1 : lane < 4 ? 2 + lane : 6 + (lane & 3));
 
   MfmaOperands oa, ob;
-  cur.next(oa);
-  double V = oa.XX, vcol = oa.X;  // :108-113: terminal value = stage N-1
-  unsigned long long suspect = 0;
+  cur.upper(oa);
+  // :108-113: terminal value = stage N-1: V = l_xx in both blocks, vc = l_x in column 2 of block 1
+  double V = odd_blocks_from_even(oa.Ca), vc = oa.Ca * mvc;
+  bool bad = false;
   auto step = [&](const MfmaOperands& o) {
-    const double Bt = o.B * bscale;
-    const double PA = CILQR_MFMA(V, o.A, 0.0);
-    const double PB = CILQR_MFMA(V, Bt, vcol);
-    const double XU = CILQR_MFMA(o.A, vcol, o.X);
-    const double UU = CILQR_MFMA(Bt, PB, o.UU);
-    const double XX = CILQR_MFMA(o.A, PA, o.XX);
-    const double UX = CILQR_MFMA(Bt, PA, 0.0);
-    const double a = readlane_f64(UU, 0), b = readlane_f64(UU, 1), d = readlane_f64(UU, 17);
+    const double P = CILQR_MFMA(V, o.AB, vc);
+    const double Db = CILQR_MFMA(o.BB, P, o.Cb);
+    const double Da = CILQR_MFMA(o.AA, P, o.Ca);
+    const double a = readlane_f64(Db, 4), b = readlane_f64(Db, 5), d = readlane_f64(Db, 21);
     const double bb = b * b;
     const double det0 = fma(a, d, -bb);
-    const bool ok = (det0 >= 0.0) & (a + d >= 0.0);
-    suspect |= __builtin_amdgcn_ballot_w64(!ok);
+    bad |= !((det0 >= 0.0) & (a + d >= 0.0));
     const double ar = a + lamb, dr = d + lamb;
     const double nr = -rcp_newton(fma(ar, dr, -bb));
     const double adj = fma(ar, m11, fma(-b, m01, dr * m00));
-    const double KK = CILQR_MFMA(adj, UX, 0.0) * nr;
-    const double KV = CILQR_MFMA(adj, UU, 0.0) * nr;
-    const double H = fma(lamb, KK, UX);
-    V = CILQR_MFMA(H, KK, XX);
-    vcol = mcol2 * CILQR_MFMA(H, KV, XU);
-    const double gv = from_kv ? KV : KK;
-    if (stores) *gp = gv;
-    gp -= RW;
+    const double Dk = CILQR_MFMA(adj, Db, 0.0) * nr;
+    const double H = odd_blocks_from_even(fma(lamb, Dk, Db));
+    double Dv = CILQR_MFMA(H, Dk, Da);
+    vc = Dv * mvc;
+    CILQR_PIN(vc);  // (the product before the copy below, so that the copy can be made in place)
+    CILQR_PIN(Dv);
+    V = odd_blocks_from_even(Dv);
+    if (stores) *gp = Dk;
+    gp -= REC;
   };
+  // two steps per trip: the lower step's operands are read while the upper one computes, the next trip's upper operands while
+  // the lower one computes; the last one or two steps are peeled so that no read reaches below the first record
   int j = N - 1;
-  for (; j >= 1; j -= 2) {
-    cur.next(ob);
+  for (; j >= 2; j -= 2) {
+    cur.lower(ob);
     step(oa);
-    if (j >= 2) cur.next(oa);
+    cur.back();
+    cur.upper(oa);
     step(ob);
   }
-  if (j == 0) step(oa);
-  return suspect == 0;
+  if (j == 1) {
+    cur.lower(ob);
+    step(oa);
+    step(ob);
+  } else {
+    step(oa);
+  }
+  return __builtin_amdgcn_ballot_w64(bad) == 0;
 }
 
 template <int KS>
@@ -506,10 +523,9 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
 
   // The production kernel runs the forward pass IN PLACE unless CILQR_FLAG_FAITHFUL_ITERS is set: with the early exit a forward
   // pass is only ever run for an accepted iteration, so its result always replaces the trajectory it started from, and the pass
-  // reads a step's old state, control and gains one step before it overwrites them (forward_fast).  No candidate buffers, and
-  // records of 14 doubles (its Riccati step forms the products with row 0 of fu from those with row 2 of fx): 4 KB less LDS per
-  // solve at N = 50 — which is what lets a CU hold six workgroups of the sampled-obstacle configuration instead of five.
-  constexpr int RECW = GENERAL ? REC : REC - 2;
+  // reads a step's old state, control and gains one step before it overwrites them (forward_fast).  No candidate buffers: 3.2 KB
+  // less LDS per solve at N = 50.
+  constexpr int RECW = REC;
   const bool twin = GENERAL || (a.flags & CILQR_FLAG_FAITHFUL_ITERS) != 0;
   double* samp = lds;
   double* Xa = samp + ((S + 1) & ~1);  // (even count: the records behind stay 16-byte aligned)
@@ -535,7 +551,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   }
   double* Ug = a.U + (size_t)b * 2 * N;
   for (int i = lane; i < 2 * N; i += WAVE) Ua[i] = Ug[i];
-  if (lane < RCST) cst[lane] = lane == 0 ? 0.0 : lane == 1 ? 1.0 : lane == 2 ? kp.dt : kp.w_vel * 2;
+  if (lane < 8) cst[(lane & 3) + (lane >> 2) * REC] = (lane & 3) == 0 ? 0.0 : (lane & 3) == 1 ? 1.0 : (lane & 3) == 2 ? kp.dt : kp.w_vel * 2;
 
   const double* wts = (TAB != 2 && a.obs_weight) ? a.obs_weight + (size_t)b * M : nullptr;
   if (TAB == 2) {
@@ -680,7 +696,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
       }
       break;
     }
-    if (!(GENERAL ? riccati<true>(kp, N, rec, kK, lamb) : riccati_mfma(kp, N, rec, kK, cst, lamb))) {
+    if (!(GENERAL ? riccati<true>(kp, N, rec, kK, lamb) : riccati_mfma(N, rec, kK, cst, lamb))) {
       if (GENERAL) { status = CILQR_EXIT_NUMERIC; break; }
       handover = true;
       break;
@@ -767,10 +783,10 @@ __global__ void unc_cost_kernel(UncArgs u, int n, const double* states, double* 
 }
 
 // Bytes of the per-solve arrays: `compact` = the production kernel without CILQR_FLAG_FAITHFUL_ITERS (forward pass in place,
-// 14-double records); otherwise candidate buffers and 16-double records.
+// no candidate buffers); otherwise with candidate buffers.
 size_t core_lds_bytes(int N, int n_samples, bool compact) {
   const size_t traj = (size_t)(N + 1) * XR + (size_t)2 * N;
-  const size_t doubles = (((size_t)n_samples + 1) & ~(size_t)1) + (compact ? 1 : 2) * traj + (size_t)N * (compact ? REC - 2 : REC) + RCST;  // gains overlay the records
+  const size_t doubles = (((size_t)n_samples + 1) & ~(size_t)1) + (compact ? 1 : 2) * traj + (size_t)N * REC + RCST;  // gains overlay the records
   return doubles * sizeof(double);
 }
 
