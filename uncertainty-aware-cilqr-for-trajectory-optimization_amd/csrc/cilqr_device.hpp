@@ -34,8 +34,14 @@ __device__ __forceinline__ double vmax(double a, double b) {
   asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+__device__ __forceinline__ double vmax_abs(double a, double b) {  // max(a, |b|): the absolute value is a source modifier
+  double r;
+  asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 // Pins a loop-invariant value in a vector register: after this the compiler cannot fold it back into a literal.
 #define CILQR_PIN(x) asm volatile("" : "+v"(x))
+#define CILQR_PIN2(x, y) asm volatile("" : "+v"(x), "+v"(y))
 
 // The parameter block as it lies in the kernel-argument segment (SolveArgs is the first kernel parameter of every solve
 // kernel), through a pointer the compiler cannot trace back to the preloaded arguments.  A phase that reads its parameters
@@ -193,16 +199,23 @@ __device__ __forceinline__ void sincos_loop(double x, double& sn, double& cs) {
 constexpr double MAX_TURN = 0.25, MAX_HEADING0 = 9.99e5;
 __device__ __forceinline__ void rotate_heading(const FwdConst& k, double delta, double& sn, double& cs) {
   const double z = delta * delta;
-  double ps = fma(z, k.sn5, k.sn4);  // sin d = d (1 - z/3! + z²/5! - z³/7! + z⁴/9! - z⁵/11!)
-  ps = fma(ps, z, k.sn3);
-  ps = fma(ps, z, k.sn2);
-  ps = fma(ps, z, k.sn1);
-  const double sd = fma(delta * z, ps, delta);
-  double pc = fma(z, k.cs6, k.cs5);  // cos d - 1 = z (-1/2 + z/4! - z²/6! + z³/8! - z⁴/10! + z⁵/12!)
+  // sin d = d (1 - z/3! + z²/5! - z³/7! + z⁴/9! - z⁵/11!);  cos d - 1 = z (-1/2 + z/4! - z²/6! + z³/8! - z⁴/10! + z⁵/12!).
+  // The two Horner chains are written interleaved and pinned that way: a dependent fp64 instruction issues every 8.5 ticks,
+  // an independent one every 5.2 (tools/ubench_exec.hip), and hipcc emits the chains one after the other otherwise.
+  double ps = fma(z, k.sn5, k.sn4);
+  double pc = fma(z, k.cs6, k.cs5);
+  CILQR_PIN2(ps, pc);
   pc = fma(pc, z, k.cs4);
+  ps = fma(ps, z, k.sn3);
+  CILQR_PIN2(ps, pc);
   pc = fma(pc, z, k.cs3);
+  ps = fma(ps, z, k.sn2);
+  CILQR_PIN2(ps, pc);
   pc = fma(pc, z, k.cs2);
+  ps = fma(ps, z, k.sn1);
+  CILQR_PIN2(ps, pc);
   pc = fma(pc, z, k.cs1);
+  const double sd = fma(delta * z, ps, delta);
   const double cdm1 = pc * z;
   const double c0 = cs, s0 = sn;
   cs = fma(c0, cdm1, fma(-s0, sd, c0));
@@ -219,7 +232,7 @@ __device__ __forceinline__ void dyn_step_loop(const FwdConst& k, State& s, doubl
   s.v = vmin(vmax(fma(a, k.dt, s.v), k.zero), k.speed_max);
   const double delta = w * k.dt;
   s.th = s.th + delta;
-  max_turn = vmax(max_turn, fabs(delta));
+  max_turn = vmax_abs(max_turn, delta);
   rotate_heading(k, delta, s.s, s.c);
 }
 

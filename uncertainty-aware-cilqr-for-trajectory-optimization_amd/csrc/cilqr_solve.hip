@@ -358,21 +358,25 @@ __device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* k
   CILQR_PIN(m00); CILQR_PIN(m01); CILQR_PIN(m11); CILQR_PIN(mvc); CILQR_PIN(lamb);
   // gains in Dk: K(0, c) in lanes 0-3, K(1, c) in lanes 16-19 (block 0); k(0), k(1) in lanes 6, 22 (column 2 of block 1)
   const bool stores = lane == 6 || lane == 22 || lane < 4 || (lane >= 16 && lane < 20);
-  double* gp = kK + (N - 1) * REC + (lane == 6 ? 0 : lane == 22 ? 1 : lane < 4 ? 2 + lane : 6 + (lane & 3));
+  double* gp = kK + (N - 1) * REC + (lane == 6 ? 0 : lane == 22 ? 1 : lane < 4 ? 2 + lane : stores ? 6 + (lane & 3) : 10 + (lane & 3));
 
   MfmaOperands oa, ob;
   cur.upper(oa);
   // :108-113: terminal value = stage N-1: V = l_xx in both blocks, vc = l_x in column 2 of block 1
   double V = odd_blocks_from_even(oa.Ca), vc = oa.Ca * mvc;
-  bool bad = false;
+  // PSD test of riccati_step<FAST> (det0 ≥ 0 and a + d ≥ 0, i.e. det0, a and d all ≥ 0), kept as sign bits: the high words of
+  // det0, a and d are OR-ed into one word over the pass, and the last det0 is looked at for NaN at the end (a NaN anywhere
+  // in the recursion stays in V_xx down to step 0).  -0.0 counts as negative: such a solve is merely handed over.
+  int signs = 0;
+  double det0 = 0.0;
   auto step = [&](const MfmaOperands& o) {
     const double P = CILQR_MFMA(V, o.AB, vc);
     const double Db = CILQR_MFMA(o.BB, P, o.Cb);
     const double Da = CILQR_MFMA(o.AA, P, o.Ca);
     const double a = readlane_f64(Db, 4), b = readlane_f64(Db, 5), d = readlane_f64(Db, 21);
     const double bb = b * b;
-    const double det0 = fma(a, d, -bb);
-    bad |= !((det0 >= 0.0) & (a + d >= 0.0));
+    det0 = fma(a, d, -bb);
+    signs |= __double2hiint(det0) | __double2hiint(a) | __double2hiint(d);
     const double ar = a + lamb, dr = d + lamb;
     const double nr = -rcp_newton(fma(ar, dr, -bb));
     const double adj = fma(ar, m11, fma(-b, m01, dr * m00));
@@ -383,7 +387,7 @@ __device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* k
     CILQR_PIN(vc);  // (the product before the copy below, so that the copy can be made in place)
     CILQR_PIN(Dv);
     V = odd_blocks_from_even(Dv);
-    if (stores) *gp = Dk;
+    *gp = Dk;  // every lane stores: the lanes that hold no gain write into slots 10-13 of the same record, which nobody reads any more
     gp -= REC;
   };
   // two steps per trip: the lower step's operands are read while the upper one computes, the next trip's upper operands while
@@ -403,7 +407,7 @@ __device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* k
   } else {
     step(oa);
   }
-  return __builtin_amdgcn_ballot_w64(bad) == 0;
+  return __builtin_amdgcn_ballot_w64(signs < 0 || !(det0 == det0)) == 0;
 }
 
 template <int KS>
@@ -420,10 +424,9 @@ __device__ __forceinline__ void fwd_step_store(const FwdConst& k, const FwdIn& c
                                                double* Xn_next) {
   double u0, u1;
   forward_step(k, c, s, max_turn, u0, u1);
-  if (threadIdx.x == 0) {
-    Un_i[0] = u0; Un_i[1] = u1;
-    Xn_next[0] = s.x; Xn_next[1] = s.y; Xn_next[2] = s.v; Xn_next[3] = s.th; Xn_next[4] = s.c; Xn_next[5] = s.s;
-  }
+  // every lane holds the same values and stores them to the same addresses: no EXEC juggling around the stores
+  Un_i[0] = u0; Un_i[1] = u1;
+  Xn_next[0] = s.x; Xn_next[1] = s.y; Xn_next[2] = s.v; Xn_next[3] = s.th; Xn_next[4] = s.c; Xn_next[5] = s.s;
 }
 
 // Phase F: iLQR::forward_pass (I/iLQR.cpp:68-86).  All lanes compute the same values; lane 0 stores; the operands of
