@@ -31,6 +31,8 @@ using namespace dev;
 
 namespace {
 
+constexpr int RECF = REC - 2;  // record width of the production kernel: p and q are not stored (they are (dt/2)·al, (dt/2)·be)
+
 __device__ __forceinline__ double readfirstlane_f64(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_readfirstlane(lo);
@@ -245,7 +247,7 @@ __device__ __forceinline__ void store_gains(double* kK, int j, const Gains& g) {
 // GENERAL = true : branching pass; false ⇒ non-finite Q_uu (the reference's backward_pass returns false).
 template <bool GENERAL>
 __device__ __forceinline__ bool riccati(const KParams& kp, int N, const double* rec, double* kK, double lamb_in) {
-  constexpr int RW = REC;
+  constexpr int RW = GENERAL ? REC : RECF;
   double dt = kp.dt, two_wvel = kp.w_vel * 2, lamb = lamb_in;
   CILQR_PIN(dt); CILQR_PIN(two_wvel); CILQR_PIN(lamb);
   Rec ra, rb;
@@ -295,14 +297,16 @@ __device__ __forceinline__ bool riccati(const KParams& kp, int N, const double* 
 //   next V = block 0 of Dv in both blocks; next vc = Dv masked to column 2 of block 1.
 // Five matrix instructions, four DPP moves and ≈ 40 others per step instead of ≈ 162 vector instructions.  V enters the first
 // product transposed: V_xx is symmetric, its two triangles agree to rounding (the reference computes both as well).  The
-// per-step operands come from the same 16-double records, each lane fetching the entry of its (block, r, c) — or a constant
+// per-step operands come from the 14-double records, each lane fetching the entry of its (block, r, c) — or a constant
 // from a small table {0, 1, dt, 2·w_vel} — through a per-lane LDS address: five ds_read_b64 per step.  Gains leave through the
 // lanes that hold them, into the layout phase F reads.  Sums are formed in another order than in riccati_step (four fused
 // multiply-adds over k per entry, structural zeros included), so results agree with it to rounding, like the other identities
 // of the production kernel; a non-finite or non-PSD Q_uu hands the solve to the GENERAL kernel exactly as before.
 #define CILQR_MFMA(xa, xb, xc) __builtin_amdgcn_mfma_f64_4x4x4f64(xa, xb, xc, 0, 0, 0)
-// Constant table behind the records: {0, 1, dt, 2·w_vel} twice, REC doubles apart — a lane that reads a constant keeps its
-// address while the others step through the records, and the two steps of one loop trip are read at immediate offsets 0 and REC.
+// Constant table behind the records: {0, 1, dt, 2·w_vel} twice, RECF doubles apart — a lane that reads a constant keeps its
+// address while the others step through the records, and the two steps of one loop trip are read at immediate offsets 0 and RECF.
+// (Records of 16 doubles would hold p and q, but a lane stride of 128 bytes puts phase L's record stores on two banks only:
+// measured +17 % on phase L; 112 bytes spread a quarter-wave's 16-byte stores over all 64 banks.)
 constexpr int RCST = REC + 4;
 
 __device__ __forceinline__ double readlane_f64(double v, int l) {
@@ -323,7 +327,7 @@ struct MfmaOperands { double AB, AA, BB, Ca, Cb; };
 struct MfmaCursor {  // this lane's read position in each operand (at the LOWER step of a pair) and its stride per pair (0: constant)
   const double *AB, *AA, *BB, *Ca, *Cb;
   int sAB, sAA, sBB, sCa, sCb;
-  __device__ __forceinline__ void upper(MfmaOperands& o) const { o.AB = AB[REC]; o.AA = AA[REC]; o.BB = BB[REC]; o.Ca = Ca[REC]; o.Cb = Cb[REC]; }
+  __device__ __forceinline__ void upper(MfmaOperands& o) const { o.AB = AB[RECF]; o.AA = AA[RECF]; o.BB = BB[RECF]; o.Ca = Ca[RECF]; o.Cb = Cb[RECF]; }
   __device__ __forceinline__ void lower(MfmaOperands& o) const { o.AB = AB[0]; o.AA = AA[0]; o.BB = BB[0]; o.Ca = Ca[0]; o.Cb = Cb[0]; }
   __device__ __forceinline__ void back() { AB -= sAB; AA -= sAA; BB -= sBB; Ca -= sCa; Cb -= sCb; }
 };
@@ -331,21 +335,21 @@ struct MfmaCursor {  // this lane's read position in each operand (at the LOWER 
 // slot: record slot (≥ 0) or constant -1 - k of this lane's entry; `low`: the record below the topmost one
 __device__ __forceinline__ void mfma_place(const double*& ptr, int& stride, int slot, const double* low, const double* cst) {
   ptr = slot >= 0 ? low + slot : cst + (-1 - slot);
-  stride = slot >= 0 ? 2 * REC : 0;
+  stride = slot >= 0 ? 2 * RECF : 0;
 }
 
-__device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* kK, const double* cst, double lamb_in) {
+__device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* kK, const double* cst, double half_dt, double lamb_in) {
   constexpr int C0 = -1, C1 = -2, CDT = -3, CW = -4;
   const int lane = threadIdx.x;
   const int e = ((lane >> 4) << 2) | (lane & 3);  // 4·r + c of this lane's entry
   const bool odd = (lane & 4) != 0;               // block 1 (or 3)
-  // record slots: 0-2 l_x, 3-5 l_xx (00, 01, 11), 6-7 l_u, 8-9 l_uu, 10-13 al, be, ga, de, 14-15 p, q (linearize)
+  // record slots: 0-2 l_x, 3-5 l_xx (00, 01, 11), 6-7 l_u, 8-9 l_uu, 10-13 al, be, ga, de (linearize)
   const int slotA = e == 0 || e == 5 || e == 10 || e == 15 ? C1 : e == 2 ? 10 : e == 6 ? 11 : e == 3 ? 12 : e == 7 ? 13 : C0;
-  const int slotB = e == 0 ? 14 : e == 4 ? 15 : e == 8 || e == 13 ? CDT : C0;
+  const int slotB = e == 0 ? 10 : e == 4 ? 11 : e == 8 || e == 13 ? CDT : C0;  // (p, q) = (dt/2)·(al, be): scaled in the step
   const int slotXX = e == 0 ? 3 : e == 1 || e == 4 ? 4 : e == 5 ? 5 : e == 10 ? CW : C0;
   const int slotX = e == 2 ? 0 : e == 6 ? 1 : e == 10 ? 2 : C0;
   const int slotUU = e == 0 ? 8 : e == 5 ? 9 : e == 2 ? 6 : e == 6 ? 7 : C0;
-  const double* low = rec + (N - 2) * REC;  // (N = 1: the record "below" is never read)
+  const double* low = rec + (N - 2) * RECF;  // (N = 1: the record "below" is never read)
   MfmaCursor cur;
   mfma_place(cur.AB, cur.sAB, odd ? slotB : slotA, low, cst);
   mfma_place(cur.AA, cur.sAA, slotA, low, cst);
@@ -354,11 +358,12 @@ __device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* k
   mfma_place(cur.Cb, cur.sCb, odd ? slotUU : C0, low, cst);
   double m00 = e == 0 ? 1.0 : 0.0, m01 = e == 1 || e == 4 ? 1.0 : 0.0, m11 = e == 5 ? 1.0 : 0.0;
   double mvc = odd && (lane & 3) == 2 ? 1.0 : 0.0;
+  double scB = e == 0 || e == 4 ? half_dt : 1.0, scAB = odd ? scB : 1.0;  // factors that turn (al, be) into (p, q) where B~ is read
   double lamb = lamb_in;
-  CILQR_PIN(m00); CILQR_PIN(m01); CILQR_PIN(m11); CILQR_PIN(mvc); CILQR_PIN(lamb);
+  CILQR_PIN(m00); CILQR_PIN(m01); CILQR_PIN(m11); CILQR_PIN(mvc); CILQR_PIN(scB); CILQR_PIN(scAB); CILQR_PIN(lamb);
   // gains in Dk: K(0, c) in lanes 0-3, K(1, c) in lanes 16-19 (block 0); k(0), k(1) in lanes 6, 22 (column 2 of block 1)
   const bool stores = lane == 6 || lane == 22 || lane < 4 || (lane >= 16 && lane < 20);
-  double* gp = kK + (N - 1) * REC + (lane == 6 ? 0 : lane == 22 ? 1 : lane < 4 ? 2 + lane : stores ? 6 + (lane & 3) : 10 + (lane & 3));
+  double* gp = kK + (N - 1) * RECF + (lane == 6 ? 0 : lane == 22 ? 1 : lane < 4 ? 2 + lane : stores ? 6 + (lane & 3) : 10 + (lane & 3));
 
   MfmaOperands oa, ob;
   cur.upper(oa);
@@ -369,7 +374,8 @@ __device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* k
   // in the recursion stays in V_xx down to step 0).  -0.0 counts as negative: such a solve is merely handed over.
   int signs = 0;
   double det0 = 0.0;
-  auto step = [&](const MfmaOperands& o) {
+  // o: this step's operands, B~ entries already scaled; n: the next step's, scaled here in the shadow of the last products
+  auto step = [&](const MfmaOperands& o, MfmaOperands& n) {
     const double P = CILQR_MFMA(V, o.AB, vc);
     const double Db = CILQR_MFMA(o.BB, P, o.Cb);
     const double Da = CILQR_MFMA(o.AA, P, o.Ca);
@@ -381,31 +387,39 @@ __device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* k
     const double nr = -rcp_newton(fma(ar, dr, -bb));
     const double adj = fma(ar, m11, fma(-b, m01, dr * m00));
     const double Dk = CILQR_MFMA(adj, Db, 0.0) * nr;
-    const double H = odd_blocks_from_even(fma(lamb, Dk, Db));
+    const double H0 = fma(lamb, Dk, Db);
+    // (p, q) of the next step from its (al, be): not before this point — hoisted to their loads the products wait for LDS
+    asm volatile("" : "+v"(n.AB), "+v"(n.BB) : "v"(H0));
+    n.AB *= scAB;
+    n.BB *= scB;
+    const double H = odd_blocks_from_even(H0);
     double Dv = CILQR_MFMA(H, Dk, Da);
     vc = Dv * mvc;
     CILQR_PIN(vc);  // (the product before the copy below, so that the copy can be made in place)
     CILQR_PIN(Dv);
     V = odd_blocks_from_even(Dv);
     *gp = Dk;  // every lane stores: the lanes that hold no gain write into slots 10-13 of the same record, which nobody reads any more
-    gp -= REC;
+    gp -= RECF;
   };
   // two steps per trip: the lower step's operands are read while the upper one computes, the next trip's upper operands while
   // the lower one computes; the last one or two steps are peeled so that no read reaches below the first record
+  oa.AB *= scAB;
+  oa.BB *= scB;
+  MfmaOperands none{0.0, 0.0, 0.0, 0.0, 0.0};
   int j = N - 1;
   for (; j >= 2; j -= 2) {
     cur.lower(ob);
-    step(oa);
+    step(oa, ob);
     cur.back();
     cur.upper(oa);
-    step(ob);
+    step(ob, oa);
   }
   if (j == 1) {
     cur.lower(ob);
-    step(oa);
-    step(ob);
+    step(oa, ob);
+    step(ob, none);
   } else {
-    step(oa);
+    step(oa, none);
   }
   return __builtin_amdgcn_ballot_w64(signs < 0 || !(det0 == det0)) == 0;
 }
@@ -528,7 +542,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   // pass is only ever run for an accepted iteration, so its result always replaces the trajectory it started from, and the pass
   // reads a step's old state, control and gains one step before it overwrites them (forward_fast).  No candidate buffers: 3.2 KB
   // less LDS per solve at N = 50.
-  constexpr int RECW = REC;
+  constexpr int RECW = GENERAL ? REC : RECF;
   const bool twin = GENERAL || (a.flags & CILQR_FLAG_FAITHFUL_ITERS) != 0;
   double* samp = lds;
   double* Xa = samp + ((S + 1) & ~1);  // (even count: the records behind stay 16-byte aligned)
@@ -554,7 +568,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   }
   double* Ug = a.U + (size_t)b * 2 * N;
   for (int i = lane; i < 2 * N; i += WAVE) Ua[i] = Ug[i];
-  if (lane < 8) cst[(lane & 3) + (lane >> 2) * REC] = (lane & 3) == 0 ? 0.0 : (lane & 3) == 1 ? 1.0 : (lane & 3) == 2 ? kp.dt : kp.w_vel * 2;
+  if (lane < 8) cst[(lane & 3) + (lane >> 2) * RECF] = (lane & 3) == 0 ? 0.0 : (lane & 3) == 1 ? 1.0 : (lane & 3) == 2 ? kp.dt : kp.w_vel * 2;
 
   const double* wts = (TAB != 2 && a.obs_weight) ? a.obs_weight + (size_t)b * M : nullptr;
   if (TAB == 2) {
@@ -699,7 +713,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
       }
       break;
     }
-    if (!(GENERAL ? riccati<true>(kp, N, rec, kK, lamb) : riccati_mfma(N, rec, kK, cst, lamb))) {
+    if (!(GENERAL ? riccati<true>(kp, N, rec, kK, lamb) : riccati_mfma(N, rec, kK, cst, 0.5 * kp.dt, lamb))) {
       if (GENERAL) { status = CILQR_EXIT_NUMERIC; break; }
       handover = true;
       break;
@@ -789,7 +803,7 @@ __global__ void unc_cost_kernel(UncArgs u, int n, const double* states, double* 
 // no candidate buffers); otherwise with candidate buffers.
 size_t core_lds_bytes(int N, int n_samples, bool compact) {
   const size_t traj = (size_t)(N + 1) * XR + (size_t)2 * N;
-  const size_t doubles = (((size_t)n_samples + 1) & ~(size_t)1) + (compact ? 1 : 2) * traj + (size_t)N * REC + RCST;  // gains overlay the records
+  const size_t doubles = (((size_t)n_samples + 1) & ~(size_t)1) + (compact ? 1 : 2) * traj + (size_t)N * (compact ? RECF : REC) + RCST;  // gains overlay the records
   return doubles * sizeof(double);
 }
 
