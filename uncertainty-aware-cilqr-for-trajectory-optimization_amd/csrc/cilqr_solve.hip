@@ -192,9 +192,15 @@ __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int
                       samp[cs], M, src.at(t), c);
     double* r = rec + t * RECW;
     r[0] = c.lx0; r[1] = c.lx1; r[2] = c.lx2; r[3] = c.l00; r[4] = c.l01; r[5] = c.l11;
-    r[6] = c.lu0; r[7] = c.lu1; r[8] = c.luu0; r[9] = c.luu1;
+    r[7] = c.lu1; r[9] = c.luu1;
     r[10] = c.al; r[11] = c.be; r[12] = c.ga; r[13] = c.de;
-    if (RECW == REC) { r[14] = c.p; r[15] = c.q; }
+    if (RECW == REC) {
+      r[6] = c.lu0; r[8] = c.luu0;
+      r[14] = c.p; r[15] = c.q;
+    } else {  // production records: acceleration in units of (dt/2)·u0 (riccati_mfma)
+      const double ih = 2.0 / kp.dt;
+      r[6] = c.lu0 * ih; r[8] = c.luu0 * (ih * ih);
+    }
   }
   if (unc) {  // uniform: a map is set — its term joins l_x, l_xx after the obstacles' (I/Constraints.cpp:188-201)
     for (int t = lane; t < N; t += WAVE) {
@@ -303,11 +309,11 @@ __device__ __forceinline__ bool riccati(const KParams& kp, int N, const double* 
 // multiply-adds over k per entry, structural zeros included), so results agree with it to rounding, like the other identities
 // of the production kernel; a non-finite or non-PSD Q_uu hands the solve to the GENERAL kernel exactly as before.
 #define CILQR_MFMA(xa, xb, xc) __builtin_amdgcn_mfma_f64_4x4x4f64(xa, xb, xc, 0, 0, 0)
-// Constant table behind the records: {0, 1, dt, 2·w_vel} twice, RECF doubles apart — a lane that reads a constant keeps its
+// Constant table behind the records: {0, 1, dt, 2·w_vel, 2} twice, RECF doubles apart — a lane that reads a constant keeps its
 // address while the others step through the records, and the two steps of one loop trip are read at immediate offsets 0 and RECF.
 // (Records of 16 doubles would hold p and q, but a lane stride of 128 bytes puts phase L's record stores on two banks only:
 // measured +17 % on phase L; 112 bytes spread a quarter-wave's 16-byte stores over all 64 banks.)
-constexpr int RCST = REC + 4;
+constexpr int RCST = REC + 6;
 
 __device__ __forceinline__ double readlane_f64(double v, int l) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -338,14 +344,14 @@ __device__ __forceinline__ void mfma_place(const double*& ptr, int& stride, int 
   stride = slot >= 0 ? 2 * RECF : 0;
 }
 
-__device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* kK, const double* cst, double half_dt, double lamb_in) {
-  constexpr int C0 = -1, C1 = -2, CDT = -3, CW = -4;
+__device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* kK, const double* cst, double inv_half_dt, double lamb_in) {
+  constexpr int C0 = -1, C1 = -2, CDT = -3, CW = -4, C2 = -5;
   const int lane = threadIdx.x;
   const int e = ((lane >> 4) << 2) | (lane & 3);  // 4·r + c of this lane's entry
   const bool odd = (lane & 4) != 0;               // block 1 (or 3)
   // record slots: 0-2 l_x, 3-5 l_xx (00, 01, 11), 6-7 l_u, 8-9 l_uu, 10-13 al, be, ga, de (linearize)
   const int slotA = e == 0 || e == 5 || e == 10 || e == 15 ? C1 : e == 2 ? 10 : e == 6 ? 11 : e == 3 ? 12 : e == 7 ? 13 : C0;
-  const int slotB = e == 0 ? 10 : e == 4 ? 11 : e == 8 || e == 13 ? CDT : C0;  // (p, q) = (dt/2)·(al, be): scaled in the step
+  const int slotB = e == 0 ? 10 : e == 4 ? 11 : e == 8 ? C2 : e == 13 ? CDT : C0;  // first column (p, q, dt, 0) / (dt/2) = (al, be, 2, 0)
   const int slotXX = e == 0 ? 3 : e == 1 || e == 4 ? 4 : e == 5 ? 5 : e == 10 ? CW : C0;
   const int slotX = e == 2 ? 0 : e == 6 ? 1 : e == 10 ? 2 : C0;
   const int slotUU = e == 0 ? 8 : e == 5 ? 9 : e == 2 ? 6 : e == 6 ? 7 : C0;
@@ -358,9 +364,10 @@ __device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* k
   mfma_place(cur.Cb, cur.sCb, odd ? slotUU : C0, low, cst);
   double m00 = e == 0 ? 1.0 : 0.0, m01 = e == 1 || e == 4 ? 1.0 : 0.0, m11 = e == 5 ? 1.0 : 0.0;
   double mvc = odd && (lane & 3) == 2 ? 1.0 : 0.0;
-  double scB = e == 0 || e == 4 ? half_dt : 1.0, scAB = odd ? scB : 1.0;  // factors that turn (al, be) into (p, q) where B~ is read
-  double lamb = lamb_in;
-  CILQR_PIN(m00); CILQR_PIN(m01); CILQR_PIN(m11); CILQR_PIN(mvc); CILQR_PIN(scB); CILQR_PIN(scAB); CILQR_PIN(lamb);
+  // lamb·I in the scaled units: diag(lamb·(2/dt)², lamb); per lane the factor of its row of K
+  double lamb = lamb_in, lamb0 = lamb_in * (inv_half_dt * inv_half_dt);
+  double lamb_row = (lane >> 4) == 0 ? lamb0 : lamb;
+  CILQR_PIN(m00); CILQR_PIN(m01); CILQR_PIN(m11); CILQR_PIN(mvc); CILQR_PIN(lamb); CILQR_PIN(lamb0); CILQR_PIN(lamb_row);
   // gains in Dk: K(0, c) in lanes 0-3, K(1, c) in lanes 16-19 (block 0); k(0), k(1) in lanes 6, 22 (column 2 of block 1)
   const bool stores = lane == 6 || lane == 22 || lane < 4 || (lane >= 16 && lane < 20);
   double* gp = kK + (N - 1) * RECF + (lane == 6 ? 0 : lane == 22 ? 1 : lane < 4 ? 2 + lane : stores ? 6 + (lane & 3) : 10 + (lane & 3));
@@ -374,8 +381,7 @@ __device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* k
   // in the recursion stays in V_xx down to step 0).  -0.0 counts as negative: such a solve is merely handed over.
   int signs = 0;
   double det0 = 0.0;
-  // o: this step's operands, B~ entries already scaled; n: the next step's, scaled here in the shadow of the last products
-  auto step = [&](const MfmaOperands& o, MfmaOperands& n) {
+  auto step = [&](const MfmaOperands& o) {
     const double P = CILQR_MFMA(V, o.AB, vc);
     const double Db = CILQR_MFMA(o.BB, P, o.Cb);
     const double Da = CILQR_MFMA(o.AA, P, o.Ca);
@@ -383,15 +389,11 @@ __device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* k
     const double bb = b * b;
     det0 = fma(a, d, -bb);
     signs |= __double2hiint(det0) | __double2hiint(a) | __double2hiint(d);
-    const double ar = a + lamb, dr = d + lamb;
+    const double ar = a + lamb0, dr = d + lamb;
     const double nr = -rcp_newton(fma(ar, dr, -bb));
     const double adj = fma(ar, m11, fma(-b, m01, dr * m00));
     const double Dk = CILQR_MFMA(adj, Db, 0.0) * nr;
-    const double H0 = fma(lamb, Dk, Db);
-    // (p, q) of the next step from its (al, be): not before this point — hoisted to their loads the products wait for LDS
-    asm volatile("" : "+v"(n.AB), "+v"(n.BB) : "v"(H0));
-    n.AB *= scAB;
-    n.BB *= scB;
+    const double H0 = fma(lamb_row, Dk, Db);
     const double H = odd_blocks_from_even(H0);
     double Dv = CILQR_MFMA(H, Dk, Da);
     vc = Dv * mvc;
@@ -403,23 +405,20 @@ __device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* k
   };
   // two steps per trip: the lower step's operands are read while the upper one computes, the next trip's upper operands while
   // the lower one computes; the last one or two steps are peeled so that no read reaches below the first record
-  oa.AB *= scAB;
-  oa.BB *= scB;
-  MfmaOperands none{0.0, 0.0, 0.0, 0.0, 0.0};
   int j = N - 1;
   for (; j >= 2; j -= 2) {
     cur.lower(ob);
-    step(oa, ob);
+    step(oa);
     cur.back();
     cur.upper(oa);
-    step(ob, oa);
+    step(ob);
   }
   if (j == 1) {
     cur.lower(ob);
-    step(oa, ob);
-    step(ob, none);
+    step(oa);
+    step(ob);
   } else {
-    step(oa, none);
+    step(oa);
   }
   return __builtin_amdgcn_ballot_w64(signs < 0 || !(det0 == det0)) == 0;
 }
@@ -434,10 +433,10 @@ __device__ __forceinline__ void load_fwd(FwdIn& o, const double* X, const double
   for (int k = 0; k < KR; ++k) o.g[k] = g[k];
 }
 
-__device__ __forceinline__ void fwd_step_store(const FwdConst& k, const FwdIn& c, State& s, double& max_turn, double* Un_i,
-                                               double* Xn_next) {
+__device__ __forceinline__ void fwd_step_store(const FwdConst& k, const FwdIn& c, State& s, double& max_turn, double inv_half_dt,
+                                               double* Un_i, double* Xn_next) {
   double u0, u1;
-  forward_step(k, c, s, max_turn, u0, u1);
+  forward_step<true>(k, c, s, max_turn, u0, u1, inv_half_dt);
   // every lane holds the same values and stores them to the same addresses: no EXEC juggling around the stores
   Un_i[0] = u0; Un_i[1] = u1;
   Xn_next[0] = s.x; Xn_next[1] = s.y; Xn_next[2] = s.v; Xn_next[3] = s.th; Xn_next[4] = s.c; Xn_next[5] = s.s;
@@ -452,6 +451,8 @@ __device__ __forceinline__ bool forward_fast(const KParams& kp, int N, const dou
                                              double* Xn, double* Un) {
   FwdConst k;
   make_fwd_const(k, kp);
+  double ihd = 2.0 / kp.dt;  // the acceleration gains are in units of (dt/2)·u0 (forward_step<true>)
+  CILQR_PIN(ihd);
   State s;
   s.x = X[0]; s.y = X[1]; s.v = X[2]; s.th = X[3]; s.c = X[4]; s.s = X[5];
   if (threadIdx.x == 0) store_state(Xn, 0, s);
@@ -461,11 +462,11 @@ __device__ __forceinline__ bool forward_fast(const KParams& kp, int N, const dou
   int i = 0;
   for (; i + 1 < N; i += 2) {
     load_fwd<KS>(fb, X, U, kK, i + 1);
-    fwd_step_store(k, fa, s, max_turn, Un + 2 * i, Xn + (i + 1) * XR);
+    fwd_step_store(k, fa, s, max_turn, ihd, Un + 2 * i, Xn + (i + 1) * XR);
     load_fwd<KS>(fa, X, U, kK, i + 2 < N ? i + 2 : i + 1);
-    fwd_step_store(k, fb, s, max_turn, Un + 2 * (i + 1), Xn + (i + 2) * XR);
+    fwd_step_store(k, fb, s, max_turn, ihd, Un + 2 * (i + 1), Xn + (i + 2) * XR);
   }
-  if (i < N) fwd_step_store(k, fa, s, max_turn, Un + 2 * i, Xn + (i + 1) * XR);
+  if (i < N) fwd_step_store(k, fa, s, max_turn, ihd, Un + 2 * i, Xn + (i + 1) * XR);
   return max_turn <= MAX_TURN;
 }
 
@@ -568,7 +569,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   }
   double* Ug = a.U + (size_t)b * 2 * N;
   for (int i = lane; i < 2 * N; i += WAVE) Ua[i] = Ug[i];
-  if (lane < 8) cst[(lane & 3) + (lane >> 2) * RECF] = (lane & 3) == 0 ? 0.0 : (lane & 3) == 1 ? 1.0 : (lane & 3) == 2 ? kp.dt : kp.w_vel * 2;
+  if (lane < 16 && (lane & 7) < 5) cst[(lane & 7) + (lane >> 3) * RECF] = (lane & 7) == 0 ? 0.0 : (lane & 7) == 1 ? 1.0 : (lane & 7) == 2 ? kp.dt : (lane & 7) == 3 ? kp.w_vel * 2 : 2.0;
 
   const double* wts = (TAB != 2 && a.obs_weight) ? a.obs_weight + (size_t)b * M : nullptr;
   if (TAB == 2) {
@@ -713,7 +714,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
       }
       break;
     }
-    if (!(GENERAL ? riccati<true>(kp, N, rec, kK, lamb) : riccati_mfma(N, rec, kK, cst, 0.5 * kp.dt, lamb))) {
+    if (!(GENERAL ? riccati<true>(kp, N, rec, kK, lamb) : riccati_mfma(N, rec, kK, cst, 2.0 / kp.dt, lamb))) {
       if (GENERAL) { status = CILQR_EXIT_NUMERIC; break; }
       handover = true;
       break;
