@@ -80,7 +80,7 @@ def test_early_exit_equals_reference_loop(cilqr, solver):
 
 
 @pytest.mark.parametrize("N,M,B,seed", [(30, 2, 128, 101), (80, 16, 128, 102), (50, 0, 64, 103), (1, 1, 8, 104), (64, 3, 32, 105),
-                                        (65, 3, 32, 106), (7, 5, 16, 107)])
+                                        (65, 3, 32, 106), (7, 5, 16, 107), (2, 1, 8, 108), (3, 2, 8, 109)])
 def test_other_shapes(cilqr, oracle, solver, N, M, B, seed):
     """Config 1 / config 5 shapes, no obstacles, horizons around the wavefront width, tiny horizons."""
     from cilqr_amd import scenes
@@ -391,6 +391,25 @@ def test_automatic_family_choice_large_batch(cilqr, oracle):
     want = _oracle_batch(oracle, 50, sub)
     _compare({k: v[:256] for k, v in got.items()}, want, TIGHT, "auto G")
     assert np.isfinite(got["U"]).all()
+
+
+def test_two_wavefronts_per_simd(cilqr, oracle):
+    """B = 2048 at N = 50: still the one-wavefront-per-solve family, two workgroups per SIMD (the library's choice for
+    N ≤ 64 and B ≤ 2 × SIMDs); first, middle and last 64 solves against the oracle, the rest finite with a sane status."""
+    from cilqr_amd import scenes
+    B = 2048
+    p = cilqr.default_params(50)
+    sc = scenes.make_static(B, 50, 4, p, 402)
+    s = cilqr.Solver(p, max_batch=B, max_horizon=50, max_obstacles=4, device=0)
+    try:
+        got = _gpu_batch(s, sc)
+    finally:
+        s.close()
+    idx = np.concatenate([np.arange(64), np.arange(1000, 1064), np.arange(B - 64, B)])
+    sub = {k: (v[idx] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in sc.items()}
+    want = _oracle_batch(oracle, 50, sub)
+    _compare({k: v[idx] for k, v in got.items()}, want, TIGHT, "two per SIMD")
+    assert np.isfinite(got["U"]).all() and (got["iters"] >= 1).all()
 
 
 # ------------------------------------------------------------------------------------------------ uncertainty blur

@@ -360,14 +360,17 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
   a.B = B; a.N = N; a.M = M; a.flags = flags;
   a.kp = h->kp;
   HIP_TRY(hipSetDevice(h->device));
-  // Kernel family by batch size: up to one solve per SIMD (1024 on an MI355X) one wavefront per solve,
-  // LDS-resident — 0.69 ms for 1024 solves of config 2; a second wavefront on a SIMD already slows that SIMD's two solves to
-  // 0.98 ms (measured at B = 1280), more than the grouped family needs for any B up to 2048 (0.82-0.83 ms).  Above, G lanes per
-  // solve with G the power of two nearest below 64·SIMDs/B (at most 32), i.e. about one wavefront per SIMD.
+  // Kernel family by batch size (measured with tools/family_shapes.py).  One wavefront per solve, LDS-resident,
+  // up to one solve per SIMD (1024 on an MI355X: 0.48 ms for config 2) — and up to two per SIMD when the horizon fits one round
+  // of lanes (N ≤ 64): since the backward pass runs on the matrix cores a second wavefront on a SIMD costs that family less
+  // than the grouped family's global-memory traffic (config-2 scenes at B = 2048: 0.68 ms against 0.84 ms; N = 30 … 50,
+  // M = 0 … 12 alike), and later workgroups fill the SIMDs that short solves leave early.  Longer horizons (N = 80: 1.43 ms
+  // against 1.34 ms at B = 1536) and larger batches go to G lanes per solve, G the power of two nearest below 64·SIMDs/B (at
+  // most 32), i.e. about one wavefront per SIMD.
   int G = 64;
   if (h->force_g == 1 || h->force_g == 2 || h->force_g == 4 || h->force_g == 8 || h->force_g == 16 || h->force_g == 32 || h->force_g == 64) {
     G = h->force_g;
-  } else if (B > h->simds && M <= 32) {
+  } else if (B > h->simds && M <= 32 && !(N <= 64 && B <= 2 * h->simds)) {
     // (with hundreds of obstacle entries per step the solve is a stream over its obstacle table: the wavefront-per-solve
     // family reads it as whole 400-640 B rows per instruction and measures ≈2x faster there — BASELINE config 3)
     G = 32;

@@ -379,7 +379,7 @@ __device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* k
   // PSD test of riccati_step<FAST> (det0 ≥ 0 and a + d ≥ 0, i.e. det0, a and d all ≥ 0), kept as sign bits: the high words of
   // det0, a and d are OR-ed into one word over the pass, and the last det0 is looked at for NaN at the end (a NaN anywhere
   // in the recursion stays in V_xx down to step 0).  -0.0 counts as negative: such a solve is merely handed over.
-  int signs = 0;
+  int signs_v = 0, signs_s = 0;  // (one word in a vector register for det0, one in a scalar register for a and d: no transfers)
   double det0 = 0.0;
   auto step = [&](const MfmaOperands& o) {
     const double P = CILQR_MFMA(V, o.AB, vc);
@@ -388,7 +388,8 @@ __device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* k
     const double a = readlane_f64(Db, 4), b = readlane_f64(Db, 5), d = readlane_f64(Db, 21);
     const double bb = b * b;
     det0 = fma(a, d, -bb);
-    signs |= __double2hiint(det0) | __double2hiint(a) | __double2hiint(d);
+    signs_v |= __double2hiint(det0);
+    signs_s |= __double2hiint(a) | __double2hiint(d);
     const double ar = a + lamb0, dr = d + lamb;
     const double nr = -rcp_newton(fma(ar, dr, -bb));
     const double adj = fma(ar, m11, fma(-b, m01, dr * m00));
@@ -420,7 +421,7 @@ __device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* k
   } else {
     step(oa);
   }
-  return __builtin_amdgcn_ballot_w64(signs < 0 || !(det0 == det0)) == 0;
+  return __builtin_amdgcn_ballot_w64((signs_v | signs_s) < 0 || !(det0 == det0)) == 0;
 }
 
 template <int KS>
