@@ -31,9 +31,9 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (cannot be collected inside this process): FETCH_SIZE
 # doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950, plus WRITE_SIZE.  Keyed by (workload, batch).
-PMC_TRAFFIC_BYTES = {("c2", 1024): 2 * 5640.64e3 + 2592e3,      # profiles/r02_solver_summary.md
-                     ("c3", 4096): 2 * 332987e3 + 114197e3,     # compact sampled form (materialised: ≈ 23 GB)
-                     ("c5", 8192): 2 * 1.70435e9 + 1.83323e9,   # the global workspace of the grouped family (r01: 8.42 GB)
+PMC_TRAFFIC_BYTES = {("c2", 1024): 2 * 5648.25e3 + 2592e3,      # profiles/r02_solver_summary.md
+                     ("c3", 4096): 2 * 330600e3 + 114228e3,     # compact sampled form (materialised: ≈ 23 GB)
+                     ("c5", 8192): 2 * 1.70531e9 + 1.83323e9,   # the global workspace of the grouped family (r01: 8.42 GB)
                      # profiles/r01_wide_rows_summary.md (KB per dispatch): the 1024^2 destination reads a 512^2 patch of the source
                      ("warp", 1024): 2 * 598.438e3 + 4096e3,
                      ("occ", 8192): 2 * 131103e3 + 65536e3}
@@ -698,11 +698,13 @@ def main():
                          "traffic_source": "profiles/r02_solver_summary.md (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
                          if (args.workload, B) in PMC_TRAFFIC_BYTES and not (args.workload == "c3" and args.materialised) else None,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch,
-                         "note": "latency/fp64-VALU-bound path: HBM fraction is tiny by design (LDS-resident solve); see fp64_valu"},
+                         "note": "issue-bound path of one wavefront per SIMD: HBM fraction is tiny by design (LDS-resident solve); see fp64_valu"},
             "fp64_valu": {"achieved_tflops_est": flops_solve * B / (kern_ms * 1e-3) / 1e12, "peak_tflops": FP64_VALU_PEAK_TF,
                           "frac": flops_solve * B / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
                           "flops_per_solve_executed": flops_solve, "mean_executed_passes": mean_passes,
                           "mean_executed_linearisations": mean_lin,
+                          "note": "algorithmic flops (SURVEY 8d) over the vector fp64 peak; the backward pass runs on v_mfma_f64_4x4x4 "
+                                  "(matrix fp64 peak 157.3 TF), whose padded 4x4x4 blocks execute more flops than counted here",
                           "reference_iteration_figure": {"flops_per_solve": flops_ref,
                                                          "tflops": flops_ref * B / (kern_ms * 1e-3) / 1e12,
                                                          "note": "counts the rejected iterations the reference loop repeats and the kernel skips"}},

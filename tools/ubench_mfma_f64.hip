@@ -75,19 +75,20 @@ int main() {
     for (int ld = 0; ld < 64; ++ld) if (h[la * 64 + ld] != 0.0) printf(" (%d:%d)", ld, (int)h[la * 64 + ld] - 1);
     printf("\n");
   }
-  // hypothesis: A_b[i][k] at lane i + 4k + 16b, B_b[k][j] at lane j + 4k + 16b, D_b[i][j] at lane j + 4i + 16b
+  // the map the solver relies on: A_b[i][k] at lane i + 4b + 16k, B_b[k][j] at lane j + 4b + 16k, D_b[i][j] at lane j + 4b + 16i
+  // (block b = lane bits 2-3, the 16-lane row = k for the inputs and i for the result)
   int bad = 0;
   for (int la = 0; la < 64; ++la) {
-    const int bl = la / 16, k = (la % 16) / 4, i = la % 4;
+    const int i = la % 4, bl = (la / 4) % 4, k = la / 16;
     for (int ld = 0; ld < 64; ++ld) {
       double want = 0.0;
-      if (ld / 16 == bl && (ld % 16) / 4 == i) { const int j = ld % 4; want = (j + 4 * k + 16 * bl) + 1.0; }
+      if ((ld / 4) % 4 == bl && ld / 16 == i) { const int j = ld % 4; want = (j + 4 * bl + 16 * k) + 1.0; }
       if (h[la * 64 + ld] != want) ++bad;
     }
   }
-  printf("layout hypothesis A[i][k]@i+4k+16b, B[k][j]@j+4k+16b, D[i][j]@j+4i+16b: %s (%d mismatches)\n", bad ? "WRONG" : "holds", bad);
+  printf("lane map A[i][k]@i+4b+16k, B[k][j]@j+4b+16k, D[i][j]@j+4b+16i: %s (%d mismatches)\n", bad ? "WRONG" : "holds", bad);
 
-  // order of accumulation: lane maps per the hypothesis; entry (0,0) of block 0: a[0][k] at lane 4k, b[k][0] at lane 4k, c at lane 0
+  // order of accumulation: entry (0,0) of block 0: a[0][k] at lane 16k, b[k][0] at lane 16k, c at lane 0
   double *pa, *pb, *pc, *pd;
   (void)hipMalloc(&pa, 512); (void)hipMalloc(&pb, 512); (void)hipMalloc(&pc, 512); (void)hipMalloc(&pd, 512);
   const double big = 9007199254740992.0;  // 2^53: c = 1 is absorbed if added to it first
@@ -95,7 +96,7 @@ int main() {
     for (int km = 0; km < 4; ++km) {
       if (kp == km) continue;
       std::vector<double> a(64, 0.0), b(64, 0.0), c(64, 0.0), r(64);
-      a[4 * kp] = big; b[4 * kp] = 1.0; a[4 * km] = -big; b[4 * km] = 1.0; c[0] = 1.0;
+      a[16 * kp] = big; b[16 * kp] = 1.0; a[16 * km] = -big; b[16 * km] = 1.0; c[0] = 1.0;
       (void)hipMemcpy(pa, a.data(), 512, hipMemcpyHostToDevice); (void)hipMemcpy(pb, b.data(), 512, hipMemcpyHostToDevice);
       (void)hipMemcpy(pc, c.data(), 512, hipMemcpyHostToDevice);
       order<<<1, 64>>>(pa, pb, pc, pd); (void)hipDeviceSynchronize();

@@ -14,15 +14,17 @@
 //                       the abscissae are equispaced and re-formed with one fma where needed)
 //   X a/b [(N+1)][6]    state records {x, y, v, theta, cos theta, sin theta}, double-buffered (X / X_new)
 //   U a/b [N][2]        controls, double-buffered (U / U_new)
-//   rec   [N][16]       per-step linearisation {l_x(3), l_xx(3), l_u(2), l_uu(2), A/B entries(6)}
+//   rec   [N][14]       per-step linearisation {l_x(3), l_xx(3), l_u(2), l_uu(2), A/B entries(4)} (16 with p, q in the GENERAL kernel)
 //   kK                  feed-forward k and feedback K of the backward pass: stored over the record of their step
+//   cst   [22]          constant entries of the matrix operands of phase R
 //   tab   [M][N][6]     obstacle table (when it fits; else the same layout in a global workspace)
 // Phases per iteration:
 //   L  lanes = timesteps: closest path sample, tracking + obstacle + control barrier derivatives, A/B entries,
 //      the stage cost of get_J, wavefront-shuffle reduction of J;
-//   R  backward Riccati recursion, sequential in t, fp64 VALU in registers, per-step operands broadcast from LDS;
-//   F  forward pass, sequential in t.
-// No MFMA: the largest contraction is 4×4×4.
+//   R  backward Riccati recursion, sequential in t: five v_mfma_f64_4x4x4_4b_f64 per step, the value function held as 4×4 blocks
+//      across the lanes, operands fetched from the records by per-lane LDS addresses (riccati_mfma); the GENERAL kernel
+//      evaluates the same recursion entry by entry on the vector ALU (riccati);
+//   F  forward pass, sequential in t, every lane computing the same values.
 #include "cilqr_device.hpp"
 
 namespace cilqr {
@@ -304,8 +306,13 @@ __device__ __forceinline__ bool riccati(const KParams& kp, int N, const double* 
 // Five matrix instructions, four DPP moves and ≈ 40 others per step instead of ≈ 162 vector instructions.  V enters the first
 // product transposed: V_xx is symmetric, its two triangles agree to rounding (the reference computes both as well).  The
 // per-step operands come from the 14-double records, each lane fetching the entry of its (block, r, c) — or a constant
-// from a small table {0, 1, dt, 2·w_vel} — through a per-lane LDS address: five ds_read_b64 per step.  Gains leave through the
-// lanes that hold them, into the layout phase F reads.  Sums are formed in another order than in riccati_step (four fused
+// from a small table — through a per-lane LDS address: five ds_read_b64 per step.  Gains leave through the lanes that hold them,
+// into the layout phase F reads.
+// Units: the first column of B is (p, q, dt, 0) = (dt/2)·(al, be, 2, 0) (I/Model.cpp:139-155 against :100-127), so the pass
+// carries the acceleration in units of (dt/2)·u0: B~'s entries are read straight from al, be and two constants, phase L stores
+// l_u(0)·(2/dt) and l_uu(0)·(2/dt)² in these records (linearize), lamb·I becomes diag(lamb·(2/dt)², lamb), H'Dk is invariant,
+// and phase F multiplies the acceleration gains by 2/dt in the instruction that adds the old control (forward_step<true>).
+// Sums are formed in another order than in riccati_step (four fused
 // multiply-adds over k per entry, structural zeros included), so results agree with it to rounding, like the other identities
 // of the production kernel; a non-finite or non-PSD Q_uu hands the solve to the GENERAL kernel exactly as before.
 #define CILQR_MFMA(xa, xb, xc) __builtin_amdgcn_mfma_f64_4x4x4f64(xa, xb, xc, 0, 0, 0)
