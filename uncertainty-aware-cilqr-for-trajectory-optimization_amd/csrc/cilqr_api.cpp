@@ -353,6 +353,7 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
   a.X_out = X_out; a.J_out = J_out; a.iters_out = iters_out; a.status_out = status_out;
   a.samp_off = nullptr; a.n_samples = 0; a.samp_w = 0.0;
   a.obs_tab = h->d_obs_tab;
+  a.fwd = h->d_ws;  // (the grouped family's workspace: 42·N + 12 doubles per solve ≥ the 16·(N + 1) needed here; never both at once)
   a.redo = h->d_redo;
   a.diag = h->diag;
   a.passes = h->passes;
@@ -423,6 +424,7 @@ int cilqr_solve_batch_sampled_device(cilqr_handle* h, void* stream, int B, int N
   a.X_out = X_out; a.J_out = J_out; a.iters_out = iters_out; a.status_out = status_out;
   a.samp_off = sample_offset; a.n_samples = n_samples; a.samp_w = sample_weight;
   a.obs_tab = h->d_obs_tab;  // n_obs·N·8 doubles per solve ≤ the n_obs·n_samples·N·6 reserved for the materialised form
+  a.fwd = h->d_ws;
   a.redo = h->d_redo;
   a.diag = h->diag;
   a.passes = h->passes;

@@ -244,12 +244,16 @@ struct FwdIn {
 // the matrix cores works with B's first column divided by dt/2 (riccati_mfma) — and `inv_half_dt` = 2/dt brings them back in
 // the instruction that adds the old control: as many instructions as the plain form.
 template <bool SCALED = false>
-__device__ __forceinline__ void forward_step(const FwdConst& k, const FwdIn& c, State& s, double& max_turn, double& u0, double& u1,
-                                             double inv_half_dt = 1.0) {
+__device__ __forceinline__ void forward_controls(const FwdIn& c, const State& s, double& u0, double& u1, double inv_half_dt = 1.0) {
   const double d0 = s.x - c.x, d1 = s.y - c.y, d2 = s.v - c.v, d3 = s.th - c.th;
   if (SCALED) u0 = fma(fma(c.g[5], d3, fma(c.g[4], d2, fma(c.g[3], d1, fma(c.g[2], d0, c.g[0])))), inv_half_dt, c.u0);
   else u0 = fma(c.g[5], d3, fma(c.g[4], d2, fma(c.g[3], d1, fma(c.g[2], d0, c.u0 + c.g[0]))));
   u1 = fma(c.g[9], d3, fma(c.g[8], d2, fma(c.g[7], d1, fma(c.g[6], d0, c.u1 + c.g[1]))));
+}
+template <bool SCALED = false>
+__device__ __forceinline__ void forward_step(const FwdConst& k, const FwdIn& c, State& s, double& max_turn, double& u0, double& u1,
+                                             double inv_half_dt = 1.0) {
+  forward_controls<SCALED>(c, s, u0, u1, inv_half_dt);
   dyn_step_loop(k, s, u0, u1, max_turn);
 }
 

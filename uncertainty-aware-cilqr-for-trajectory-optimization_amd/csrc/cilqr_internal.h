@@ -55,6 +55,7 @@ struct SolveArgs {
   int32_t n_samples;       // nominal trajectories of the M obstacles, every sample weighs samp_w, and the wavefront family runs.
   double samp_w;           // n_samples == 0: ordinary obstacles
   double* obs_tab;      // workspace: [B][M][N][6] (sampled: [B][M][N][8])
+  double* fwd;          // workspace of the one-wavefront-per-solve family: [B][N + 1][16] forward-pass records (cilqr_solve.hip)
   int32_t* redo;        // workspace: [B] hand-over flags from the fast kernel to the general kernel
   unsigned long long* diag;  // null, or [B][8] phase cycle totals (diagnostic instantiation)
   int32_t* passes;      // null, or [B]: backward+forward passes each solve actually executed (cilqr_set_pass_count_buffer)

@@ -34,6 +34,10 @@ using namespace dev;
 namespace {
 
 constexpr int RECF = REC - 2;  // record width of the production kernel: p and q are not stored (they are (dt/2)·al, (dt/2)·be)
+// Forward-pass record of the production kernel, in GLOBAL memory (SolveArgs::fwd, [N + 1][FREC] per solve, the last one a dump):
+// {k(2), K(2x4)} written by phase R, {x, y, v, theta, u0, u1} of the old trajectory written by phase L; phase F reads a step's
+// record with two s_load_dwordx16 (forward_smem).
+constexpr int FREC = 16;
 
 __device__ __forceinline__ double readfirstlane_f64(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -182,12 +186,18 @@ struct SampledSource {
 template <int RECW, typename Source>
 __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int lane, const double* samp, int S,
                                             const SampleGrid& grid, const double* X, const double* U, double* rec,
-                                            const Source& src, const UncArgs* unc, UncPose upose, int ub) {
+                                            const Source& src, const UncArgs* unc, UncPose upose, int ub, double* fwd) {
   double Jpart = 0.0;
   for (int t = lane; t < N; t += WAVE) {
     const double* xr = X + t * XR;
     const double* xn = X + (t + 1) * XR;
     const double px = xr[0], py = xr[1];
+    if (RECW == RECF) {  // production kernel: the forward pass reads the old state and control of step t through the scalar path
+      double2* q = reinterpret_cast<double2*>(fwd + t * FREC + 10);
+      q[0] = make_double2(px, py);
+      q[1] = make_double2(xr[2], xr[3]);
+      q[2] = make_double2(U[2 * t], U[2 * t + 1]);
+    }
     const int cs = closest_sample(S, grid, px, py, LdsSamples{samp, grid.xf, grid.dxs});
     Rec c;
     Jpart += lin_step<true, Source::kPaired>(kp, px, py, xr[2], xr[4], xr[5], U[2 * t], U[2 * t + 1], xn[2], xn[4], xn[5], fma(grid.dxs, (double)cs, grid.xf),
@@ -351,7 +361,7 @@ __device__ __forceinline__ void mfma_place(const double*& ptr, int& stride, int 
   stride = slot >= 0 ? 2 * RECF : 0;
 }
 
-__device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* kK, const double* cst, double inv_half_dt, double lamb_in) {
+__device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* fwd, const double* cst, double inv_half_dt, double lamb_in) {
   constexpr int C0 = -1, C1 = -2, CDT = -3, CW = -4, C2 = -5;
   const int lane = threadIdx.x;
   const int e = ((lane >> 4) << 2) | (lane & 3);  // 4·r + c of this lane's entry
@@ -376,8 +386,12 @@ __device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* k
   double lamb_row = (lane >> 4) == 0 ? lamb0 : lamb;
   CILQR_PIN(m00); CILQR_PIN(m01); CILQR_PIN(m11); CILQR_PIN(mvc); CILQR_PIN(lamb); CILQR_PIN(lamb0); CILQR_PIN(lamb_row);
   // gains in Dk: K(0, c) in lanes 0-3, K(1, c) in lanes 16-19 (block 0); k(0), k(1) in lanes 6, 22 (column 2 of block 1)
+  // They go to the forward-pass records in global memory; the lanes that hold no gain write into the dump record behind the last.
   const bool stores = lane == 6 || lane == 22 || lane < 4 || (lane >= 16 && lane < 20);
-  double* gp = kK + (N - 1) * RECF + (lane == 6 ? 0 : lane == 22 ? 1 : lane < 4 ? 2 + lane : stores ? 6 + (lane & 3) : 10 + (lane & 3));
+  unsigned goff = stores ? (unsigned)(((N - 1) * FREC + (lane == 6 ? 0 : lane == 22 ? 1 : lane < 4 ? 2 + lane : 6 + (lane & 3))) * 8)
+                         : (unsigned)((N * FREC + (lane & 15)) * 8);
+  const unsigned gstride = stores ? FREC * 8 : 0;
+  char* const gbase = reinterpret_cast<char*>(fwd);
 
   MfmaOperands oa, ob;
   cur.upper(oa);
@@ -408,8 +422,8 @@ __device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* k
     CILQR_PIN(vc);  // (the product before the copy below, so that the copy can be made in place)
     CILQR_PIN(Dv);
     V = odd_blocks_from_even(Dv);
-    *gp = Dk;  // every lane stores: the lanes that hold no gain write into slots 10-13 of the same record, which nobody reads any more
-    gp -= RECF;
+    *reinterpret_cast<double*>(gbase + goff) = Dk;
+    goff -= gstride;
   };
   // two steps per trip: the lower step's operands are read while the upper one computes, the next trip's upper operands while
   // the lower one computes; the last one or two steps are peeled so that no read reaches below the first record
@@ -448,6 +462,79 @@ __device__ __forceinline__ void fwd_step_store(const FwdConst& k, const FwdIn& c
   // every lane holds the same values and stores them to the same addresses: no EXEC juggling around the stores
   Un_i[0] = u0; Un_i[1] = u1;
   Xn_next[0] = s.x; Xn_next[1] = s.y; Xn_next[2] = s.v; Xn_next[3] = s.th; Xn_next[4] = s.c; Xn_next[5] = s.s;
+}
+
+// ---- Phase F with its operands through the scalar path (production kernel) --------------------------------------------------------
+// The forward pass needs 16 doubles per step (old state and control, gains), the same for all lanes.  As broadcast LDS reads
+// that was 8 ds_read2_b64 per step beside 4 stores — and the LDS pipeline of a CU serves its four SIMDs: measured with
+// tools/phase_cycles.py at 1 / 2 / 4 wavefronts per CU (B = 256 / 512 / 1024) phase F took 437 / 461 / 529 ticks per step (365
+// with the reads removed), phase R with its 6 LDS instructions 378 / 385 / 387.  Neither narrowing EXEC around the LDS
+// instructions (by branches: 583; from one inline-assembly block per step: 536) nor 128-bit reads (553) changed that: what
+// counts is the number of LDS instructions in flight on the CU.  So the operands take the scalar path instead: phases L and R
+// write them to a 128-byte record per step in global memory (FREC), phase F reads a step with two s_load_dwordx16 into scalar
+// registers, one step ahead, and uses them as the scalar operand of its vector instructions (one per instruction: every
+// product of the pass has one loaded and one computed factor).  Hand-over: s_waitcnt vmcnt(0) — the vector stores have reached
+// L2 — and s_dcache_inv before the first scalar load (checked on its own by tools/ubench_smem.hip); a one-dword load three
+// steps ahead warms the scalar cache, whose lines (64 B) are otherwise all first touches.  hipcc does not see these loads: every
+// use lies behind f_swait, which carries the registers as in/out operands of the s_waitcnt that makes them valid.
+typedef double d8_t __attribute__((ext_vector_type(8)));
+struct FwdS { d8_t lo, hi; };  // lo = {k0, k1, K00..K03, K10, K11}, hi = {K12, K13, x, y, v, theta, u0, u1}
+__device__ __forceinline__ void f_sload_first(FwdS& r, const double* p) {
+  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(r.lo), "=&s"(r.hi) : "s"(p) : "memory");
+}
+// The next record into the SAME registers: as in/out operands, so that every use of the old values lies before this point and
+// one set of 32 scalar registers serves the whole pass (two sets alive at once do not fit beside the kernel's other scalars).
+__device__ __forceinline__ void f_sload_next(FwdS& r, const double* p) {
+  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "+s"(r.lo), "+s"(r.hi) : "s"(p) : "memory");
+}
+__device__ __forceinline__ void f_swarm(int& w, const double* p) {  // touch both lines of a later record
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, 0x40" : "+s"(w) : "s"(p) : "memory");
+}
+__device__ __forceinline__ void f_swait(FwdS& r, int& w) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.lo), "+s"(r.hi), "+s"(w) : : "memory");
+}
+__device__ __forceinline__ void f_sunpack(FwdIn& o, const FwdS& r) {
+  o.g[0] = r.lo[0]; o.g[1] = r.lo[1]; o.g[2] = r.lo[2]; o.g[3] = r.lo[3]; o.g[4] = r.lo[4]; o.g[5] = r.lo[5];
+  o.g[6] = r.lo[6]; o.g[7] = r.lo[7]; o.g[8] = r.hi[0]; o.g[9] = r.hi[1];
+  o.x = r.hi[2]; o.y = r.hi[3]; o.v = r.hi[4]; o.th = r.hi[5]; o.u0 = r.hi[6]; o.u1 = r.hi[7];
+}
+
+// Phase F: iLQR::forward_pass (I/iLQR.cpp:68-86), production kernel.  A step: wait for its record; the controls from the
+// record and the running state (forward_controls); request the next record; the dynamics (dyn_step_loop), ≈ 250 ticks in which
+// the request completes; results to LDS (every lane stores the same values to the same addresses), where the next phase L reads
+// them by lanes.  Returns false if a step turned the heading by more than MAX_TURN (rotate_heading): the results are then not to
+// be used and the solve is handed to the GENERAL kernel.
+__device__ __forceinline__ bool forward_smem(const KParams& kp, int N, const double* X, const double* fwd, double* Xn, double* Un) {
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");  // L's and R's record stores → scalar loads
+  FwdConst k;
+  make_fwd_const(k, kp);
+  double ihd = 2.0 / kp.dt;  // the acceleration gains are in units of (dt/2)·u0 (forward_controls<true>)
+  CILQR_PIN(ihd);
+  State s;
+  s.x = X[0]; s.y = X[1]; s.v = X[2]; s.th = X[3]; s.c = X[4]; s.s = X[5];
+  store_state(Xn, 0, s);
+  double max_turn = 0.0;  // (the first heading was checked by the rollout)
+  auto recp = [&](int j) { return fwd + (size_t)(j < N ? j : N) * FREC; };  // (past the end: the dump record)
+  FwdS r;
+  FwdIn c;
+  int w = 0;
+  f_sload_first(r, recp(0));
+  f_swarm(w, recp(1));
+  f_swait(r, w);
+  f_swarm(w, recp(2));
+  for (int i = 0; i < N; ++i) {
+    f_swait(r, w);
+    f_sunpack(c, r);
+    double u0, u1;
+    forward_controls<true>(c, s, u0, u1, ihd);
+    f_sload_next(r, recp(i + 1));
+    f_swarm(w, recp(i + 3));
+    dyn_step_loop(k, s, u0, u1, max_turn);
+    Un[2 * i] = u0; Un[2 * i + 1] = u1;
+    store_state(Xn, i + 1, s);
+  }
+  f_swait(r, w);  // (the request of the last step: the dump record)
+  return max_turn <= MAX_TURN;
 }
 
 // Phase F: iLQR::forward_pass (I/iLQR.cpp:68-86).  All lanes compute the same values; lane 0 stores; the operands of
@@ -561,6 +648,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   double* rec = Ub + 2 * N;
   double* kK = rec;  // the gains overlay the records (store_gains)
   double* cst = rec + N * RECW;  // {0, 1, dt, 2·w_vel}: riccati_mfma's constant entries
+  double* fwd = a.fwd + (size_t)b * (N + 1) * FREC;  // forward-pass records of this solve (production kernel)
   double* tab = TAB == 1 ? cst + RCST : a.obs_tab + (size_t)b * M * (TAB == 2 ? NOMF : TABF) * N;
   double* off = cst + RCST;  // TAB == 2: offset records [o][s][OFFF], then rmax[o]
   double* rmax = off + (size_t)M * a.n_samples * OFFF;
@@ -699,8 +787,8 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
       const KParams kpl = phase_params();  // phase-local read of the parameter block (cilqr_device.hpp)
       const UncArgs* unc = has_unc ? &phase_args().unc : nullptr;  // uniform: a map is set (cilqr_set_uncertainty_map*)
       if (TAB == 2) part = linearize<RECW>(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, SampledSource{tab, off, rmax, Xc, N, a.n_samples, M, a.samp_w, kpl.ego_front, kpl.ego_rear,
-                                                     sqrt(1.0 + 64.0 / kpl.q2_front), sqrt(1.0 + 64.0 / kpl.q2_rear)}, unc, upose, b);
-      else part = linearize<RECW>(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, TabSource<TAB == 0>{tab, wts, N, kpl.w_obstacle}, unc, upose, b);
+                                                     sqrt(1.0 + 64.0 / kpl.q2_front), sqrt(1.0 + 64.0 / kpl.q2_rear)}, unc, upose, b, fwd);
+      else part = linearize<RECW>(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, TabSource<TAB == 0>{tab, wts, N, kpl.w_obstacle}, unc, upose, b, fwd);
       J_new = readfirstlane_f64(wave_sum(part));
     }
     j_valid = true;
@@ -722,7 +810,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
       }
       break;
     }
-    if (!(GENERAL ? riccati<true>(kp, N, rec, kK, lamb) : riccati_mfma(N, rec, kK, cst, 2.0 / kp.dt, lamb))) {
+    if (!(GENERAL ? riccati<true>(kp, N, rec, kK, lamb) : riccati_mfma(N, rec, fwd, cst, 2.0 / kp.dt, lamb))) {
       if (GENERAL) { status = CILQR_EXIT_NUMERIC; break; }
       handover = true;
       break;
@@ -733,7 +821,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
     if (DIAG) ++n_R;
     if (GENERAL) {
       forward_general(kp, N, Xc, Uc, kK, Xn, Un);
-    } else if (!forward_fast<RECW>(KParams(phase_params()), N, Xc, Uc, kK, Xn, Un)) {
+    } else if (!forward_smem(KParams(phase_params()), N, Xc, fwd, Xn, Un)) {
       handover = true;
       break;
     }
