@@ -185,9 +185,20 @@ struct SampledSource {
 // RECW: doubles per stored record.
 template <int RECW, typename Source>
 __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int lane, const double* samp, int S,
-                                            const SampleGrid& grid, const double* X, const double* U, double* rec,
+                                            const SampleGrid& grid, double* X, const double* U, double* rec,
                                             const Source& src, const UncArgs* unc, UncPose upose, int ub, double* fwd) {
   double Jpart = 0.0;
+  if (RECW == RECF) {
+    // Production kernel: the forward pass stores {x, y, v, theta} only — its cos/sin store was the last LDS instruction of a step
+    // and the next step's wait paid its latency (34 ticks per step, 50 steps per pass) — so the cos/sin columns are filled here,
+    // by lanes, from theta (35 instructions per call; the headings are within sincos_loop's range: rollout_fast, MAX_TURN).
+    for (int t = lane; t <= N; t += WAVE) {
+      double sn, cs;
+      sincos_loop(X[t * XR + 3], sn, cs);
+      X[t * XR + 4] = cs; X[t * XR + 5] = sn;
+    }
+    __syncthreads();
+  }
   for (int t = lane; t < N; t += WAVE) {
     const double* xr = X + t * XR;
     const double* xn = X + (t + 1) * XR;
@@ -531,7 +542,8 @@ __device__ __forceinline__ bool forward_smem(const KParams& kp, int N, const dou
     f_swarm(w, recp(i + 3));
     dyn_step_loop(k, s, u0, u1, max_turn);
     Un[2 * i] = u0; Un[2 * i + 1] = u1;
-    store_state(Xn, i + 1, s);
+    double* xo = Xn + (i + 1) * XR;  // (cos/sin columns: filled by the next phase L)
+    xo[0] = s.x; xo[1] = s.y; xo[2] = s.v; xo[3] = s.th;
   }
   f_swait(r, w);  // (the request of the last step: the dump record)
   return max_turn <= MAX_TURN;
