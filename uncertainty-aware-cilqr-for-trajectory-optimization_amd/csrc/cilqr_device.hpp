@@ -222,8 +222,9 @@ __device__ __forceinline__ void rotate_heading(const FwdConst& k, double delta, 
   sn = fma(s0, cdm1, fma(c0, sd, s0));
 }
 
-// Model::forward_simulate on the in-loop constants.  max_turn: running maximum of |w·dt| (see rotate_heading).
-__device__ __forceinline__ void dyn_step_loop(const FwdConst& k, State& s, double u0, double u1, double& max_turn) {
+// Model::forward_simulate on the in-loop constants, in two halves: position, speed and heading (returns the turn delta = w·dt);
+// then cos/sin of the new heading.  max_turn: running maximum of |w·dt| (see rotate_heading).
+__device__ __forceinline__ double dyn_pose_loop(const FwdConst& k, State& s, double u0, double u1, double& max_turn) {
   const double a = vmax(vmin(u0, k.acc_max), k.acc_min);
   const double w = vmax(vmin(u1, s.v * k.yaw_hi), s.v * k.yaw_lo);
   const double adv = fma(a, k.half_dt2, s.v * k.dt);
@@ -233,6 +234,10 @@ __device__ __forceinline__ void dyn_step_loop(const FwdConst& k, State& s, doubl
   const double delta = w * k.dt;
   s.th = s.th + delta;
   max_turn = vmax_abs(max_turn, delta);
+  return delta;
+}
+__device__ __forceinline__ void dyn_step_loop(const FwdConst& k, State& s, double u0, double u1, double& max_turn) {
+  const double delta = dyn_pose_loop(k, s, u0, u1, max_turn);
   rotate_heading(k, delta, s.s, s.c);
 }
 

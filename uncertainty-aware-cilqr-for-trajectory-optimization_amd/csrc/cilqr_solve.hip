@@ -485,9 +485,10 @@ __device__ __forceinline__ void fwd_step_store(const FwdConst& k, const FwdIn& c
 // write them to a 128-byte record per step in global memory (FREC), phase F reads a step with two s_load_dwordx16 into scalar
 // registers, one step ahead, and uses them as the scalar operand of its vector instructions (one per instruction: every
 // product of the pass has one loaded and one computed factor).  Hand-over: s_waitcnt vmcnt(0) — the vector stores have reached
-// L2 — and s_dcache_inv before the first scalar load (checked on its own by tools/ubench_smem.hip); a one-dword load three
-// steps ahead warms the scalar cache, whose lines (64 B) are otherwise all first touches.  hipcc does not see these loads: every
-// use lies behind f_swait, which carries the registers as in/out operands of the s_waitcnt that makes them valid.
+// L2 — and s_dcache_inv before the first scalar load (checked on its own by tools/ubench_smem.hip).  Every record is a first touch
+// for the scalar cache; the ≈ 250 ticks between a request and its wait cover that (one-dword loads two to five steps ahead, to
+// warm the cache, made the step slower: 430 ticks against 400).  hipcc does not see these loads: every use lies behind f_swait,
+// which carries the registers as in/out operands of the s_waitcnt that makes them valid.
 typedef double d8_t __attribute__((ext_vector_type(8)));
 struct FwdS { d8_t lo, hi; };  // lo = {k0, k1, K00..K03, K10, K11}, hi = {K12, K13, x, y, v, theta, u0, u1}
 __device__ __forceinline__ void f_sload_first(FwdS& r, const double* p) {
@@ -498,11 +499,8 @@ __device__ __forceinline__ void f_sload_first(FwdS& r, const double* p) {
 __device__ __forceinline__ void f_sload_next(FwdS& r, const double* p) {
   asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "+s"(r.lo), "+s"(r.hi) : "s"(p) : "memory");
 }
-__device__ __forceinline__ void f_swarm(int& w, const double* p) {  // touch both lines of a later record
-  asm volatile("s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, 0x40" : "+s"(w) : "s"(p) : "memory");
-}
-__device__ __forceinline__ void f_swait(FwdS& r, int& w) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.lo), "+s"(r.hi), "+s"(w) : : "memory");
+__device__ __forceinline__ void f_swait(FwdS& r) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.lo), "+s"(r.hi) : : "memory");
 }
 __device__ __forceinline__ void f_sunpack(FwdIn& o, const FwdS& r) {
   o.g[0] = r.lo[0]; o.g[1] = r.lo[1]; o.g[2] = r.lo[2]; o.g[3] = r.lo[3]; o.g[4] = r.lo[4]; o.g[5] = r.lo[5];
@@ -528,24 +526,23 @@ __device__ __forceinline__ bool forward_smem(const KParams& kp, int N, const dou
   auto recp = [&](int j) { return fwd + (size_t)(j < N ? j : N) * FREC; };  // (past the end: the dump record)
   FwdS r;
   FwdIn c;
-  int w = 0;
   f_sload_first(r, recp(0));
-  f_swarm(w, recp(1));
-  f_swait(r, w);
-  f_swarm(w, recp(2));
   for (int i = 0; i < N; ++i) {
-    f_swait(r, w);
+    f_swait(r);
     f_sunpack(c, r);
     double u0, u1;
     forward_controls<true>(c, s, u0, u1, ihd);
     f_sload_next(r, recp(i + 1));
-    f_swarm(w, recp(i + 3));
-    dyn_step_loop(k, s, u0, u1, max_turn);
     Un[2 * i] = u0; Un[2 * i + 1] = u1;
+    const double delta = dyn_pose_loop(k, s, u0, u1, max_turn);
     double* xo = Xn + (i + 1) * XR;  // (cos/sin columns: filled by the next phase L)
     xo[0] = s.x; xo[1] = s.y; xo[2] = s.v; xo[3] = s.th;
+    // the rotation last: its ≈ 100 ticks cover the latency of the stores above, which the next step's s_waitcnt lgkmcnt(0) —
+    // the only safe wait with scalar loads in flight — would otherwise pay
+    rotate_heading(k, delta, s.s, s.c);
+    CILQR_PIN2(s.s, s.c);
   }
-  f_swait(r, w);  // (the request of the last step: the dump record)
+  f_swait(r);  // (the request of the last step: the dump record)
   return max_turn <= MAX_TURN;
 }
 
