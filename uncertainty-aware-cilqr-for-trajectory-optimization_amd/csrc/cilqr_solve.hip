@@ -183,13 +183,13 @@ struct SampledSource {
 
 // Phase L.  Returns this lane's partial of J over its timesteps.  M = number of obstacle entries per step.
 // RECW: doubles per stored record.
-template <int RECW, typename Source>
+template <int RECW, bool FSMEM, typename Source>
 __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int lane, const double* samp, int S,
                                             const SampleGrid& grid, double* X, const double* U, double* rec,
                                             const Source& src, const UncArgs* unc, UncPose upose, int ub, double* fwd) {
   double Jpart = 0.0;
-  if (RECW == RECF) {
-    // Production kernel: the forward pass stores {x, y, v, theta} only — its cos/sin store was the last LDS instruction of a step
+  if (FSMEM) {
+    // Scalar-path forward pass (forward_smem): it stores {x, y, v, theta} only — its cos/sin store was the last LDS instruction of a step
     // and the next step's wait paid its latency (34 ticks per step, 50 steps per pass) — so the cos/sin columns are filled here,
     // by lanes, from theta (35 instructions per call; the headings are within sincos_loop's range: rollout_fast, MAX_TURN).
     for (int t = lane; t <= N; t += WAVE) {
@@ -203,7 +203,7 @@ __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int
     const double* xr = X + t * XR;
     const double* xn = X + (t + 1) * XR;
     const double px = xr[0], py = xr[1];
-    if (RECW == RECF) {  // production kernel: the forward pass reads the old state and control of step t through the scalar path
+    if (FSMEM) {  // the forward pass reads the old state and control of step t through the scalar path
       double2* q = reinterpret_cast<double2*>(fwd + t * FREC + 10);
       q[0] = make_double2(px, py);
       q[1] = make_double2(xr[2], xr[3]);
@@ -372,7 +372,8 @@ __device__ __forceinline__ void mfma_place(const double*& ptr, int& stride, int 
   stride = slot >= 0 ? 2 * RECF : 0;
 }
 
-__device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* fwd, const double* cst, double inv_half_dt, double lamb_in) {
+template <bool FSMEM>
+__device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* kK, double* fwd, const double* cst, double inv_half_dt, double lamb_in) {
   constexpr int C0 = -1, C1 = -2, CDT = -3, CW = -4, C2 = -5;
   const int lane = threadIdx.x;
   const int e = ((lane >> 4) << 2) | (lane & 3);  // 4·r + c of this lane's entry
@@ -397,12 +398,15 @@ __device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* f
   double lamb_row = (lane >> 4) == 0 ? lamb0 : lamb;
   CILQR_PIN(m00); CILQR_PIN(m01); CILQR_PIN(m11); CILQR_PIN(mvc); CILQR_PIN(lamb); CILQR_PIN(lamb0); CILQR_PIN(lamb_row);
   // gains in Dk: K(0, c) in lanes 0-3, K(1, c) in lanes 16-19 (block 0); k(0), k(1) in lanes 6, 22 (column 2 of block 1)
-  // They go to the forward-pass records in global memory; the lanes that hold no gain write into the dump record behind the last.
+  // FSMEM: they go to the forward-pass records in global memory, the lanes that hold no gain write into the dump record behind
+  // the last.  Otherwise: over the first 10 doubles of the step's record in LDS, the other lanes into its slots 10-13, which
+  // nobody reads any more.  Every lane stores either way: no EXEC change.
   const bool stores = lane == 6 || lane == 22 || lane < 4 || (lane >= 16 && lane < 20);
-  unsigned goff = stores ? (unsigned)(((N - 1) * FREC + (lane == 6 ? 0 : lane == 22 ? 1 : lane < 4 ? 2 + lane : 6 + (lane & 3))) * 8)
-                         : (unsigned)((N * FREC + (lane & 15)) * 8);
+  const int gslot = lane == 6 ? 0 : lane == 22 ? 1 : lane < 4 ? 2 + lane : 6 + (lane & 3);
+  unsigned goff = stores ? (unsigned)(((N - 1) * FREC + gslot) * 8) : (unsigned)((N * FREC + (lane & 15)) * 8);
   const unsigned gstride = stores ? FREC * 8 : 0;
   char* const gbase = reinterpret_cast<char*>(fwd);
+  double* gp = kK + (N - 1) * RECF + (stores ? gslot : 10 + (lane & 3));
 
   MfmaOperands oa, ob;
   cur.upper(oa);
@@ -433,8 +437,13 @@ __device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* f
     CILQR_PIN(vc);  // (the product before the copy below, so that the copy can be made in place)
     CILQR_PIN(Dv);
     V = odd_blocks_from_even(Dv);
-    *reinterpret_cast<double*>(gbase + goff) = Dk;
-    goff -= gstride;
+    if (FSMEM) {
+      *reinterpret_cast<double*>(gbase + goff) = Dk;
+      goff -= gstride;
+    } else {
+      *gp = Dk;
+      gp -= RECF;
+    }
   };
   // two steps per trip: the lower step's operands are read while the upper one computes, the next trip's upper operands while
   // the lower one computes; the last one or two steps are peeled so that no read reaches below the first record
@@ -648,6 +657,10 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   // reads a step's old state, control and gains one step before it overwrites them (forward_fast).  No candidate buffers: 3.2 KB
   // less LDS per solve at N = 50.
   constexpr int RECW = GENERAL ? REC : RECF;
+  // Forward-pass operands through the scalar path (forward_smem) where the obstacle table lies in LDS; where a solve streams its
+  // obstacles from global memory (TAB 0, 2) the records would compete with that stream for L2 and the scalar loads miss: config 3
+  // measured 0.95 M solves/s with them against 1.05 M without.
+  constexpr bool FSMEM = !GENERAL && TAB == 1;
   const bool twin = GENERAL || (a.flags & CILQR_FLAG_FAITHFUL_ITERS) != 0;
   double* samp = lds;
   double* Xa = samp + ((S + 1) & ~1);  // (even count: the records behind stay 16-byte aligned)
@@ -795,9 +808,9 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
       double part;
       const KParams kpl = phase_params();  // phase-local read of the parameter block (cilqr_device.hpp)
       const UncArgs* unc = has_unc ? &phase_args().unc : nullptr;  // uniform: a map is set (cilqr_set_uncertainty_map*)
-      if (TAB == 2) part = linearize<RECW>(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, SampledSource{tab, off, rmax, Xc, N, a.n_samples, M, a.samp_w, kpl.ego_front, kpl.ego_rear,
+      if (TAB == 2) part = linearize<RECW, FSMEM>(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, SampledSource{tab, off, rmax, Xc, N, a.n_samples, M, a.samp_w, kpl.ego_front, kpl.ego_rear,
                                                      sqrt(1.0 + 64.0 / kpl.q2_front), sqrt(1.0 + 64.0 / kpl.q2_rear)}, unc, upose, b, fwd);
-      else part = linearize<RECW>(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, TabSource<TAB == 0>{tab, wts, N, kpl.w_obstacle}, unc, upose, b, fwd);
+      else part = linearize<RECW, FSMEM>(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, TabSource<TAB == 0>{tab, wts, N, kpl.w_obstacle}, unc, upose, b, fwd);
       J_new = readfirstlane_f64(wave_sum(part));
     }
     j_valid = true;
@@ -819,7 +832,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
       }
       break;
     }
-    if (!(GENERAL ? riccati<true>(kp, N, rec, kK, lamb) : riccati_mfma(N, rec, fwd, cst, 2.0 / kp.dt, lamb))) {
+    if (!(GENERAL ? riccati<true>(kp, N, rec, kK, lamb) : riccati_mfma<FSMEM>(N, rec, kK, fwd, cst, 2.0 / kp.dt, lamb))) {
       if (GENERAL) { status = CILQR_EXIT_NUMERIC; break; }
       handover = true;
       break;
@@ -830,7 +843,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
     if (DIAG) ++n_R;
     if (GENERAL) {
       forward_general(kp, N, Xc, Uc, kK, Xn, Un);
-    } else if (!forward_smem(KParams(phase_params()), N, Xc, fwd, Xn, Un)) {
+    } else if (!(FSMEM ? forward_smem(KParams(phase_params()), N, Xc, fwd, Xn, Un) : forward_fast<RECW>(KParams(phase_params()), N, Xc, Uc, kK, Xn, Un))) {
       handover = true;
       break;
     }
@@ -962,7 +975,7 @@ hipError_t launch_solve_wave(const SolveArgs& a, hipStream_t stream) {
   const size_t lds = solve_lds_bytes(a.N, a.kp.n_samples);  // the larger layout: limits and the table decision hold for both kernels
   // Keep the obstacle table in LDS while a workgroup stays within 32 KiB (≥ 5 solves resident per CU of 160 KiB).
   const size_t tab_bytes = (size_t)a.M * TABF * a.N * sizeof(double);
-  const bool tab_lds = a.n_samples == 0 && a.M > 0 && lds + tab_bytes <= 32 * 1024;
+  const bool tab_lds = a.n_samples == 0 && lds + tab_bytes <= 32 * 1024;  // (M = 0: an empty table fits)
   if (a.n_samples > 0) {  // sampled obstacles: offset records in LDS, nominal records in the global workspace
     const size_t extra = solve_sampled_lds_bytes(a.M, a.n_samples);
     if (lds + extra > SOLVE_LDS_MAX) return hipErrorInvalidValue;  // checked by the caller
