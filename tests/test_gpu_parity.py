@@ -378,11 +378,11 @@ def test_grouped_kernels_match_oracle(cilqr, oracle, G):
 
 
 def test_automatic_family_choice_large_batch(cilqr, oracle):
-    """B = 4096 > 1024 takes the grouped family automatically (G = 16); a 256-solve sample is checked against the oracle."""
+    """B = 6000 > 4 solves per SIMD takes the grouped family automatically (G = 8); a 256-solve sample is checked against the oracle."""
     from cilqr_amd import scenes
     p = cilqr.default_params(50)
-    sc = scenes.make_static(4096, 50, 4, p, 401)
-    s = cilqr.Solver(p, max_batch=4096, max_horizon=50, max_obstacles=4, device=0)
+    sc = scenes.make_static(6000, 50, 4, p, 401)
+    s = cilqr.Solver(p, max_batch=6000, max_horizon=50, max_obstacles=4, device=0)
     try:
         got = _gpu_batch(s, sc)
     finally:
@@ -393,22 +393,23 @@ def test_automatic_family_choice_large_batch(cilqr, oracle):
     assert np.isfinite(got["U"]).all()
 
 
-def test_two_wavefronts_per_simd(cilqr, oracle):
-    """B = 2048 at N = 50: still the one-wavefront-per-solve family, two workgroups per SIMD (the library's choice for
-    N ≤ 64 and B ≤ 2 × SIMDs); first, middle and last 64 solves against the oracle, the rest finite with a sane status."""
+@pytest.mark.parametrize("B,N,M", [(2048, 50, 4), (4096, 50, 4), (2048, 80, 16)])
+def test_several_wavefronts_per_simd(cilqr, oracle, B, N, M):
+    """Batches of two to four solves per SIMD still take the one-wavefront-per-solve family (the library's choice for
+    B ≤ 2 × SIMDs, and for N ≤ 64 up to 4 × SIMDs); N = 80 / M = 16 is the instantiation with the obstacle table in global
+    memory.  First, middle and last 64 solves against the oracle, the rest finite with a sane status."""
     from cilqr_amd import scenes
-    B = 2048
-    p = cilqr.default_params(50)
-    sc = scenes.make_static(B, 50, 4, p, 402)
-    s = cilqr.Solver(p, max_batch=B, max_horizon=50, max_obstacles=4, device=0)
+    p = cilqr.default_params(N)
+    sc = scenes.make_static(B, N, M, p, 402)
+    s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M, device=0)
     try:
         got = _gpu_batch(s, sc)
     finally:
         s.close()
     idx = np.concatenate([np.arange(64), np.arange(1000, 1064), np.arange(B - 64, B)])
     sub = {k: (v[idx] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in sc.items()}
-    want = _oracle_batch(oracle, 50, sub)
-    _compare({k: v[idx] for k, v in got.items()}, want, TIGHT, "two per SIMD")
+    want = _oracle_batch(oracle, N, sub)
+    _compare({k: v[idx] for k, v in got.items()}, want, TIGHT, "several per SIMD")
     assert np.isfinite(got["U"]).all() and (got["iters"] >= 1).all()
 
 

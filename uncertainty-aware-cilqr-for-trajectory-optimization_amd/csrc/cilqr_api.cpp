@@ -361,17 +361,17 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
   a.B = B; a.N = N; a.M = M; a.flags = flags;
   a.kp = h->kp;
   HIP_TRY(hipSetDevice(h->device));
-  // Kernel family by batch size (measured with tools/family_shapes.py).  One wavefront per solve, LDS-resident,
-  // up to one solve per SIMD (1024 on an MI355X: 0.48 ms for config 2) — and up to two per SIMD when the horizon fits one round
-  // of lanes (N ≤ 64): since the backward pass runs on the matrix cores a second wavefront on a SIMD costs that family less
-  // than the grouped family's global-memory traffic (config-2 scenes at B = 2048: 0.68 ms against 0.84 ms; N = 30 … 50,
-  // M = 0 … 12 alike), and later workgroups fill the SIMDs that short solves leave early.  Longer horizons (N = 80: 1.43 ms
-  // against 1.34 ms at B = 1536) and larger batches go to G lanes per solve, G the power of two nearest below 64·SIMDs/B (at
-  // most 32), i.e. about one wavefront per SIMD.
+  // Kernel family by batch size (measured with tools/family_shapes.py, profiles/r02_family_shapes.txt).  One
+  // wavefront per solve, LDS-resident, up to two solves per SIMD (2048 on an MI355X) whatever the horizon, and up to four when
+  // the horizon fits one round of lanes (N ≤ 64): since the backward pass runs on the matrix cores and the forward pass takes its
+  // operands through the scalar path, further wavefronts on a SIMD cost that family less than the grouped family pays in
+  // global-memory traffic, and later workgroups fill the SIMDs that short solves leave early (config-2 scenes: B = 2048 0.65 ms
+  // against 0.84 ms grouped, B = 4096 0.92 against 1.10; N = 80 at B = 2048 1.28 against 1.41, at B = 4096 2.29 against 1.69).
+  // Beyond that G lanes per solve, G the power of two nearest below 64·SIMDs/B (at most 32), i.e. about one wavefront per SIMD.
   int G = 64;
   if (h->force_g == 1 || h->force_g == 2 || h->force_g == 4 || h->force_g == 8 || h->force_g == 16 || h->force_g == 32 || h->force_g == 64) {
     G = h->force_g;
-  } else if (B > h->simds && M <= 32 && !(N <= 64 && B <= 2 * h->simds)) {
+  } else if (B > 2 * h->simds && M <= 32 && !(N <= 64 && B <= 4 * h->simds)) {
     // (with hundreds of obstacle entries per step the solve is a stream over its obstacle table: the wavefront-per-solve
     // family reads it as whole 400-640 B rows per instruction and measures ≈2x faster there — BASELINE config 3)
     G = 32;
