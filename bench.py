@@ -31,9 +31,9 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (cannot be collected inside this process): FETCH_SIZE
 # doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950, plus WRITE_SIZE.  Keyed by (workload, batch).
-PMC_TRAFFIC_BYTES = {("c2", 1024): 2 * 5648.25e3 + 2592e3,      # profiles/r02_solver_summary.md
-                     ("c3", 4096): 2 * 330600e3 + 114228e3,     # compact sampled form (materialised: ≈ 23 GB)
-                     ("c5", 8192): 2 * 1.70531e9 + 1.83323e9,   # the global workspace of the grouped family (r01: 8.42 GB)
+PMC_TRAFFIC_BYTES = {("c2", 1024): 2 * 12388.9e3 + 10090.1e3,   # profiles/r02_solver_summary.md (forward-pass records through L2 included)
+                     ("c3", 4096): 2 * 331031e3 + 114248e3,     # compact sampled form (materialised: ≈ 23 GB)
+                     ("c5", 8192): 2 * 1.70466e9 + 1.83323e9,   # the global workspace of the grouped family (r01: 8.42 GB)
                      # profiles/r01_wide_rows_summary.md (KB per dispatch): the 1024^2 destination reads a 512^2 patch of the source
                      ("warp", 1024): 2 * 598.438e3 + 4096e3,
                      ("occ", 8192): 2 * 131103e3 + 65536e3}
