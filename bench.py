@@ -710,6 +710,11 @@ def main():
                                                          "note": "counts the rejected iterations the reference loop repeats and the kernel skips"}},
             "min_cost": {"J": best[0], "global_index": best[1]},
         }
+        if args.workload == "c2" and B == 1024:  # PMC pass of the same command (profiles/r02_solver_summary.md, per launch)
+            out["issue"] = {"instruction_issue_cycles": 64.4e6, "wavefront_cycles": 100.8e6, "frac": 64.4 / 100.8,
+                            "valu_insts": 46.0e6, "salu_insts": 5.6e6, "lds_insts": 3.6e6,
+                            "note": "one wavefront per SIMD on a serial chain: the path is bound by the issue rate of a lone wavefront "
+                                    "(one instruction per 5.2 ticks, a matrix instruction 16.2), SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES"}
         # SURVEY §8(d) also asks for the host-buffer entry point (H2D + kernel + D2H); reported, never `value`
         reps = (5 if M <= 16 else 1) if world == 1 else 0
         if reps:
