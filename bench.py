@@ -31,7 +31,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (cannot be collected inside this process): FETCH_SIZE
 # doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950, plus WRITE_SIZE.  Keyed by (workload, batch).
-PMC_TRAFFIC_BYTES = {("c2", 1024): 2 * 12388.9e3 + 10090.1e3,   # profiles/r02_solver_summary.md (forward-pass records through L2 included)
+PMC_TRAFFIC_BYTES = {("c2", 1024): 2 * 12309.8e3 + 10008.8e3,   # profiles/r02_solver_summary.md (forward-pass records through L2 included)
                      ("c3", 4096): 2 * 331031e3 + 114248e3,     # compact sampled form (materialised: ≈ 23 GB)
                      ("c5", 8192): 2 * 1.70466e9 + 1.83323e9,   # the global workspace of the grouped family (r01: 8.42 GB)
                      # profiles/r01_wide_rows_summary.md (KB per dispatch): the 1024^2 destination reads a 512^2 patch of the source
@@ -711,8 +711,8 @@ def main():
             "min_cost": {"J": best[0], "global_index": best[1]},
         }
         if args.workload == "c2" and B == 1024:  # PMC pass of the same command (profiles/r02_solver_summary.md, per launch)
-            out["issue"] = {"instruction_issue_cycles": 64.4e6, "wavefront_cycles": 100.8e6, "frac": 64.4 / 100.8,
-                            "valu_insts": 46.0e6, "salu_insts": 5.6e6, "lds_insts": 3.6e6,
+            out["issue"] = {"instruction_issue_cycles": 64.4e6, "wavefront_cycles": 98.4e6, "frac": 64.4 / 98.4,
+                            "valu_insts": 46.2e6, "salu_insts": 5.6e6, "lds_insts": 3.5e6,
                             "note": "one wavefront per SIMD on a serial chain: the path is bound by the issue rate of a lone wavefront "
                                     "(one instruction per 5.2 ticks, a matrix instruction 16.2), SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES"}
         # SURVEY §8(d) also asks for the host-buffer entry point (H2D + kernel + D2H); reported, never `value`
