@@ -76,6 +76,13 @@ __device__ __forceinline__ double wave_sum_uniform(double v) {
   v += dpp_f64<0x140>(v);  // row_mirror
   return (readlane_any_f64(v, 0) + readlane_any_f64(v, 16)) + (readlane_any_f64(v, 32) + readlane_any_f64(v, 48));
 }
+__device__ __forceinline__ double wave_max_uniform(double v) {  // the same scheme for the maximum (NaN-free inputs)
+  v = fmax(v, dpp_f64<0xB1>(v));
+  v = fmax(v, dpp_f64<0x4E>(v));
+  v = fmax(v, dpp_f64<0x141>(v));
+  v = fmax(v, dpp_f64<0x140>(v));
+  return fmax(fmax(readlane_any_f64(v, 0), readlane_any_f64(v, 16)), fmax(readlane_any_f64(v, 32), readlane_any_f64(v, 48)));
+}
 
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
@@ -638,10 +645,10 @@ __device__ __forceinline__ bool rollout_fast(const KParams& kp, int N, const dou
   const bool th0_ok = fabs(s.th) < MAX_HEADING0;
   double max_turn = 0.0;
   sincos_loop(s.th, s.s, s.c);
-  if (threadIdx.x == 0) store_state(X, 0, s);
+  store_state(X, 0, s);  // (every lane holds the same values and stores them to the same addresses: no EXEC change)
   for (int i = 0; i < N; ++i) {
     dyn_step_loop(k, s, U[2 * i], U[2 * i + 1], max_turn);
-    if (threadIdx.x == 0) store_state(X, i + 1, s);
+    store_state(X, i + 1, s);
   }
   return th0_ok && max_turn <= MAX_TURN;
 }
@@ -793,7 +800,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
       const double d = fabs(samp[q + 1] - samp[q]);
       m = fmax(m, d == d ? d : __builtin_huge_val());
     }
-    grid.dmax = readfirstlane_f64(wave_max(m));
+    grid.dmax = wave_max_uniform(m);
   }
 
   UncPose upose{0, 0, 1, 0};
