@@ -587,7 +587,8 @@ __device__ __forceinline__ bool forward_smem(const KParams& kp, int N, const dou
   return max_turn <= MAX_TURN;
 }
 
-// Phase F: iLQR::forward_pass (I/iLQR.cpp:68-86).  All lanes compute the same values; lane 0 stores; the operands of
+// Phase F: iLQR::forward_pass (I/iLQR.cpp:68-86), operands from LDS (the production instantiations that stream their obstacles
+// from global memory; forward_smem otherwise).  All lanes compute and store the same values; the operands of
 // step i+1 (old state, old control, gains) are read while step i computes (two steps per trip, no register copies).
 // Returns false if a step turned the heading by more than MAX_TURN (rotate_heading, cilqr_device.hpp): the results are then
 // not to be used and the solve is handed to the GENERAL kernel.
