@@ -413,6 +413,31 @@ def test_several_wavefronts_per_simd(cilqr, oracle, B, N, M):
     assert np.isfinite(got["U"]).all() and (got["iters"] >= 1).all()
 
 
+def test_schedule_hint_changes_nothing_but_the_order(cilqr):
+    """A batch beyond one solve per SIMD is dispatched longest-first by the pass counts of the previous call (same batch size,
+    same stream).  Every call must return bit-identical results — the first (identity order), the second (hinted) and a third
+    after the scenes were shuffled, when the hint is stale — and every solve must be written exactly once."""
+    from cilqr_amd import scenes
+    B, N, M = 3000, 50, 4
+    p = cilqr.default_params(N)
+    sc = scenes.make_static(B, N, M, p, 403)
+    s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M, device=0)
+    try:
+        first = _gpu_batch(s, sc)
+        second = _gpu_batch(s, sc)
+        perm = np.random.default_rng(5).permutation(B)
+        scp = dict(sc)
+        for k in ("x0", "U", "poly", "xplan_fl", "obs_pose", "obs_dim"):
+            scp[k] = np.ascontiguousarray(sc[k][perm])
+        third = _gpu_batch(s, scp)
+    finally:
+        s.close()
+    for k in ("U", "X", "J", "iters", "status"):
+        assert np.array_equal(first[k], second[k]), k
+        assert np.array_equal(first[k][perm], third[k]), k
+    assert (first["iters"] >= 1).all() and np.isfinite(first["U"]).all()
+
+
 # ------------------------------------------------------------------------------------------------ uncertainty blur
 def _ulp32_diff(a, b):
     """Distance in float32 ulps between same-shaped arrays; NaN pairs count as 0, NaN vs number as huge."""

@@ -67,6 +67,25 @@ hipError_t dmalloc(T** p, size_t n) {
 
 }  // namespace
 
+// The one-wavefront-per-solve family with a schedule hint.  A batch of more solves than SIMDs is dispatched in workgroup order,
+// and its launch ends when the last workgroup does: a 20-pass solve that starts among the last costs its full length on top of
+// everything else (config-2 scenes at B = 4096: 0.91 ms as given, 0.53 ms with the longest solves first; config 3: 3.8 → 2.4 ms,
+// tools/schedule_order.py).  Pass counts are not known in advance — but a planner solves nearly the same scenes tick after tick,
+// so each call records its solves' pass counts and a small kernel sorts them into the NEXT call's dispatch order (same batch
+// size, same stream; otherwise, and in a first call, the order is the identity).  Any order gives the same results: a solve
+// depends on nothing but its own inputs.  CILQR_NO_SCHEDULE_HINT in the environment at create switches it off.
+static int launch_wave_scheduled(cilqr_handle* h, cilqr::SolveArgs& a, void* stream) {
+  const bool hinted = !h->hint_off && a.B > h->simds;
+  a.order = hinted && h->hint_B == a.B && h->hint_stream == stream ? h->d_order : nullptr;
+  a.hint_passes = hinted ? h->d_hint_passes : nullptr;
+  HIP_TRY(cilqr::launch_solve_wave(a, (hipStream_t)stream));
+  if (hinted) {
+    HIP_TRY(cilqr::launch_schedule_order(h->d_hint_passes, a.B, h->d_order, (hipStream_t)stream));
+    h->hint_B = a.B; h->hint_stream = stream;
+  }
+  return CILQR_OK;
+}
+
 extern "C" {
 
 int cilqr_abi_version(void) { return CILQR_ABI_VERSION; }
@@ -164,6 +183,10 @@ int cilqr_create(const cilqr_params* p, int max_batch, int max_horizon, int max_
   if (err == hipSuccess) err = dmalloc(&h->d_obs_tab, Bpad * M * N * 6);
   if (err == hipSuccess) err = dmalloc(&h->d_ws, cilqr::solve_groups_ws_doubles(max_batch, max_horizon));
   if (err == hipSuccess) err = dmalloc(&h->d_redo, B);
+  if (err == hipSuccess) err = dmalloc(&h->d_hint_passes, B);
+  if (err == hipSuccess) err = dmalloc(&h->d_order, B);
+  h->hint_B = 0; h->hint_stream = nullptr;
+  h->hint_off = getenv("CILQR_NO_SCHEDULE_HINT") != nullptr;
   if (err == hipSuccess) err = dmalloc(&h->d_pair, (size_t)2);
   if (err == hipSuccess) err = dmalloc(&h->d_triple, (size_t)3);
   if (err == hipSuccess) err = dmalloc(&h->d_gather, (size_t)3);
@@ -195,7 +218,7 @@ int cilqr_destroy(cilqr_handle* h) {
   if (h->stage) (void)hipHostFree(h->stage);
   for (void* p : h->scratch)
     if (p) (void)hipFree(p);
-  void* ptrs[] = {h->d_poses, h->d_unc_layer, h->d_triple, h->d_gather, h->d_arena, h->d_obs_tab, h->d_ws, h->d_redo, h->d_pair, h->d_src, h->d_dst, h->d_bbox, h->d_oob, h->d_occ_steps};
+  void* ptrs[] = {h->d_poses, h->d_unc_layer, h->d_triple, h->d_gather, h->d_arena, h->d_obs_tab, h->d_ws, h->d_redo, h->d_hint_passes, h->d_order, h->d_pair, h->d_src, h->d_dst, h->d_bbox, h->d_oob, h->d_occ_steps};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -354,6 +377,7 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
   a.samp_off = nullptr; a.n_samples = 0; a.samp_w = 0.0;
   a.obs_tab = h->d_obs_tab;
   a.fwd = h->d_ws;  // (the grouped family's workspace: 42·N + 12 doubles per solve ≥ the 16·(N + 1) needed here; never both at once)
+  a.order = nullptr; a.hint_passes = nullptr;
   a.redo = h->d_redo;
   a.diag = h->diag;
   a.passes = h->passes;
@@ -380,8 +404,8 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
   if (G == 64 && cilqr::solve_lds_bytes(N, h->kp.n_samples) > cilqr::SOLVE_LDS_MAX)
     return fail(CILQR_ERR_UNSUPPORTED, "cilqr_solve_batch: horizon %d needs %zu bytes of LDS per solve (limit %zu)", N,
                 cilqr::solve_lds_bytes(N, h->kp.n_samples), cilqr::SOLVE_LDS_MAX);
-  if (G == 64) HIP_TRY(cilqr::launch_solve_wave(a, (hipStream_t)stream));
-  else HIP_TRY(cilqr::launch_solve_groups(a, G, h->d_ws, (hipStream_t)stream));
+  if (G == 64) return launch_wave_scheduled(h, a, stream);
+  HIP_TRY(cilqr::launch_solve_groups(a, G, h->d_ws, (hipStream_t)stream));
   return CILQR_OK;
 }
 
@@ -432,8 +456,7 @@ int cilqr_solve_batch_sampled_device(cilqr_handle* h, void* stream, int B, int N
   a.B = B; a.N = N; a.M = n_obs; a.flags = flags;
   a.kp = h->kp;
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(cilqr::launch_solve_wave(a, (hipStream_t)stream));  // the LDS-resident family at every batch size
-  return CILQR_OK;
+  return launch_wave_scheduled(h, a, stream);  // the LDS-resident family at every batch size
 }
 
 int cilqr_solve_batch_sampled(cilqr_handle* h, int B, int N, int n_obs, int n_samples, const double* x0, double* U,

@@ -67,6 +67,12 @@ struct cilqr_handle {
   double* d_obs_tab;
   double* d_ws;      // workspace of the G-lanes-per-solve kernel family
   int32_t* d_redo;
+  // schedule hint of the one-wavefront-per-solve family: passes of the previous call and the dispatch order built from them
+  int32_t* d_hint_passes;
+  int32_t* d_order;
+  int hint_B;          // batch size the order is valid for (0: none)
+  void* hint_stream;   // stream it was built on (a call on another stream does not use it)
+  int hint_off;        // environment CILQR_NO_SCHEDULE_HINT at create
   int force_g;       // 0 = automatic; else 1,2,4,8,16,32 or 64 (test hook: environment CILQR_FORCE_G at create)
   double* d_pair;
   // warp staging (grown on demand by the host-pointer warp entry point only)

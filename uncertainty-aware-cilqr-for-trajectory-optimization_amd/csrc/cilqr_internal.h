@@ -59,6 +59,9 @@ struct SolveArgs {
   int32_t* redo;        // workspace: [B] hand-over flags from the fast kernel to the general kernel
   unsigned long long* diag;  // null, or [B][8] phase cycle totals (diagnostic instantiation)
   int32_t* passes;      // null, or [B]: backward+forward passes each solve actually executed (cilqr_set_pass_count_buffer)
+  // Dispatch order of the one-wavefront-per-solve family for batches beyond one solve per SIMD (cilqr_api.cpp, schedule hint):
+  const int32_t* order;  // null, or [B]: workgroup i runs solve order[i] (a permutation: longest solves of the previous call first)
+  int32_t* hint_passes;  // null, or [B]: passes of each solve of THIS call, from which the next call's order is built
   int32_t B, N, M;
   uint32_t flags;
   KParams kp;
@@ -68,6 +71,7 @@ struct SolveArgs {
 // Launchers (defined in the .hip files). All are asynchronous on `stream`.
 // One wavefront per solve, LDS-resident (cilqr_solve.hip).
 hipError_t launch_solve_wave(const SolveArgs& a, hipStream_t stream);
+hipError_t launch_schedule_order(const int32_t* passes, int B, int32_t* order, hipStream_t stream);  // passes descending
 size_t solve_lds_bytes(int N, int n_samples);
 constexpr size_t SOLVE_LDS_MAX = 160 * 1024;  // LDS of one CU: the horizon bound of the wavefront family
 size_t solve_sampled_lds_bytes(int n_obs, int n_samples);   // additional LDS of the sampled-obstacle mode

@@ -676,7 +676,9 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
     tk = now_;                                           \
   }
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int b = blockIdx.x;
+  if ((int)blockIdx.x >= a.B) return;
+  // dispatch order: cilqr_api.cpp, schedule hint (wave-uniform; said so to the compiler, which loads it through a vector register)
+  const int b = __builtin_amdgcn_readfirstlane(a.order ? a.order[blockIdx.x] : (int)blockIdx.x);
   const int lane = threadIdx.x;
   const KParams kp = a.kp;
   const int N = a.N, M = a.M, S = kp.n_samples;
@@ -896,7 +898,11 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   }
 
   if (!GENERAL) {
-    if (lane == 0) phase_args().redo[b] = handover ? 1 : 0;
+    int32_t* const hint = phase_args().hint_passes;
+    if (lane == 0) {
+      phase_args().redo[b] = handover ? 1 : 0;
+      if (handover && hint) hint[b] = 63;  // redone by the GENERAL kernel: to the front of the next call's order
+    }
     if (handover) return;  // outputs (and the in/out U) untouched: the GENERAL kernel starts from the same inputs
   }
 
@@ -915,6 +921,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
     if (ae.iters_out) ae.iters_out[b] = iters;
     if (ae.status_out) ae.status_out[b] = status;
     if (ae.passes) ae.passes[b] = n_pass;
+    if (ae.hint_passes && !GENERAL) ae.hint_passes[b] = n_pass;
   }
   if (DIAG && lane == 0 && a.diag) {
     const unsigned long long now_ = __builtin_readcyclecounter();
@@ -990,6 +997,35 @@ size_t solve_sampled_lds_bytes(int n_obs, int n_samples) {
   return ((size_t)n_obs * n_samples * OFFF + (size_t)2 * n_obs) * sizeof(double);  // offset records + rmax + constant-shape flags
 }
 size_t solve_sampled_tab_doubles(int n_obs, int N) { return (size_t)n_obs * NOMF * N; }
+
+// Dispatch order for the next call: solve indices sorted by pass count, descending (counting sort, one workgroup; ties in any
+// order — every permutation gives the same results, the order only decides which solves start first).
+__global__ __launch_bounds__(1024) void schedule_order_kernel(const int32_t* passes, int B, int32_t* order) {
+  __shared__ int cnt[64], base[64];
+  const int tid = threadIdx.x;
+  if (tid < 64) cnt[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < B; i += 1024) {
+    const int p = passes[i];
+    atomicAdd(&cnt[63 - (p < 0 ? 0 : p > 63 ? 63 : p)], 1);  // bucket 0 = the longest
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int k = 0; k < 64; ++k) { base[k] = acc; acc += cnt[k]; }
+  }
+  __syncthreads();
+  for (int i = tid; i < B; i += 1024) {
+    const int p = passes[i];
+    order[atomicAdd(&base[63 - (p < 0 ? 0 : p > 63 ? 63 : p)], 1)] = i;
+  }
+}
+
+hipError_t launch_schedule_order(const int32_t* passes, int B, int32_t* order, hipStream_t stream) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(schedule_order_kernel, dim3(1), dim3(1024), 0, stream, passes, B, order);
+  return hipGetLastError();
+}
 
 hipError_t launch_unc_cost(const UncArgs& u, int n, const double* states, double* cost, double* vx, double* mx, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
