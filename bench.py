@@ -692,7 +692,7 @@ def main():
             "config": {"workload": wl + ", inputs resident in HBM, + min-cost selection",
                        "batch_per_gpu": B, "horizon": N, "obstacles": M, "mean_reference_iterations": mean_iters,
                        "parallelism": "scene-sharded x%d, one ncclAllGather of 24 B per rank behind cilqr_argmin_global_device" % world},
-            "roofline": {"bound": "hbm", "kernel": "cilqr_solve_kernel" if (B <= 2048 or M > 32 or (N <= 64 and B <= 4096)) else "cilqr_solve_groups_fast", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "cilqr_solve_kernel" if (B <= 2048 or M > 32 or (N <= 64 and B <= 8192)) else "cilqr_solve_groups_fast", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if (args.workload == "c3" and args.materialised) else PMC_TRAFFIC_BYTES.get((args.workload, B)),
                          "traffic_source": "profiles/r02_solver_summary.md (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"

@@ -378,11 +378,11 @@ def test_grouped_kernels_match_oracle(cilqr, oracle, G):
 
 
 def test_automatic_family_choice_large_batch(cilqr, oracle):
-    """B = 6000 > 4 solves per SIMD takes the grouped family automatically (G = 8); a 256-solve sample is checked against the oracle."""
+    """B = 9000 > 8 solves per SIMD takes the grouped family automatically (G = 4); a 256-solve sample is checked against the oracle."""
     from cilqr_amd import scenes
     p = cilqr.default_params(50)
-    sc = scenes.make_static(6000, 50, 4, p, 401)
-    s = cilqr.Solver(p, max_batch=6000, max_horizon=50, max_obstacles=4, device=0)
+    sc = scenes.make_static(9000, 50, 4, p, 401)
+    s = cilqr.Solver(p, max_batch=9000, max_horizon=50, max_obstacles=4, device=0)
     try:
         got = _gpu_batch(s, sc)
     finally:
@@ -393,10 +393,10 @@ def test_automatic_family_choice_large_batch(cilqr, oracle):
     assert np.isfinite(got["U"]).all()
 
 
-@pytest.mark.parametrize("B,N,M", [(2048, 50, 4), (4096, 50, 4), (2048, 80, 16)])
+@pytest.mark.parametrize("B,N,M", [(2048, 50, 4), (8192, 50, 4), (2048, 80, 16)])
 def test_several_wavefronts_per_simd(cilqr, oracle, B, N, M):
-    """Batches of two to four solves per SIMD still take the one-wavefront-per-solve family (the library's choice for
-    B ≤ 2 × SIMDs, and for N ≤ 64 up to 4 × SIMDs); N = 80 / M = 16 is the instantiation with the obstacle table in global
+    """Batches of two to eight solves per SIMD still take the one-wavefront-per-solve family (the library's choice for
+    B ≤ 2 × SIMDs, and for N ≤ 64 up to 8 × SIMDs); N = 80 / M = 16 is the instantiation with the obstacle table in global
     memory.  First, middle and last 64 solves against the oracle, the rest finite with a sane status."""
     from cilqr_amd import scenes
     p = cilqr.default_params(N)

@@ -35,7 +35,7 @@ def run(N, M, B, force):
 
 shapes = [(30, 2), (50, 0), (50, 4), (50, 8), (50, 12), (80, 4), (80, 8), (80, 16), (120, 4)]
 for N, M in shapes:
-    for B in (1536, 2048, 4096, 8192):
+    for B in (2048, 4096, 8192, 16384):
         a, ia = run(N, M, B, 0)
         b, ib = run(N, M, B, 64)
         print("N=%3d M=%2d B=%5d  default %.3f ms | wavefront family %.3f ms  (mean iterations %.1f / %.1f)" % (N, M, B, a, b, ia, ib), flush=True)

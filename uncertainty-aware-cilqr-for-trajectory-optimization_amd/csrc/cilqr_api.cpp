@@ -386,16 +386,16 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
   a.kp = h->kp;
   HIP_TRY(hipSetDevice(h->device));
   // Kernel family by batch size (measured with tools/family_shapes.py, profiles/r02_family_shapes.txt).  One
-  // wavefront per solve, LDS-resident, up to two solves per SIMD (2048 on an MI355X) whatever the horizon, and up to four when
-  // the horizon fits one round of lanes (N ≤ 64): since the backward pass runs on the matrix cores and the forward pass takes its
-  // operands through the scalar path, further wavefronts on a SIMD cost that family less than the grouped family pays in
-  // global-memory traffic, and later workgroups fill the SIMDs that short solves leave early (config-2 scenes: B = 2048 0.65 ms
-  // against 0.84 ms grouped, B = 4096 0.92 against 1.10; N = 80 at B = 2048 1.28 against 1.41, at B = 4096 2.29 against 1.69).
-  // Beyond that G lanes per solve, G the power of two nearest below 64·SIMDs/B (at most 32), i.e. about one wavefront per SIMD.
+  // wavefront per solve, LDS-resident, up to two solves per SIMD (2048 on an MI355X) whatever the horizon, and up to eight when
+  // the horizon fits one round of lanes (N ≤ 64): since the backward pass runs on the matrix cores, the forward pass takes its
+  // operands through the scalar path and the workgroups are dispatched longest-first (schedule hint above), further wavefronts
+  // on a SIMD cost that family less than the grouped family pays in global-memory traffic (config-2 scenes: B = 4096 0.53 ms
+  // against 1.10 ms grouped, B = 8192 0.96-0.99 against 1.38-1.42; M = 0 and M = 8 at B = 8192 5-7 % the other way; N = 80 at
+  // B = 4096 2.25 against 1.73).  Beyond that G lanes per solve, G the power of two nearest below 64·SIMDs/B (at most 32).
   int G = 64;
   if (h->force_g == 1 || h->force_g == 2 || h->force_g == 4 || h->force_g == 8 || h->force_g == 16 || h->force_g == 32 || h->force_g == 64) {
     G = h->force_g;
-  } else if (B > 2 * h->simds && M <= 32 && !(N <= 64 && B <= 4 * h->simds)) {
+  } else if (B > 2 * h->simds && M <= 32 && !(N <= 64 && B <= 8 * h->simds)) {
     // (with hundreds of obstacle entries per step the solve is a stream over its obstacle table: the wavefront-per-solve
     // family reads it as whole 400-640 B rows per instruction and measures ≈2x faster there — BASELINE config 3)
     G = 32;
