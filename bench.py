@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (cannot be collected inside this process): FETCH_SIZE
 # doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950, plus WRITE_SIZE.  Keyed by (workload, batch).
 PMC_TRAFFIC_BYTES = {("c2", 1024): 2 * 12309.8e3 + 10008.8e3,   # profiles/r02_solver_summary.md (forward-pass records through L2 included)
-                     ("c3", 4096): 2 * 331031e3 + 114248e3,     # compact sampled form (materialised: ≈ 23 GB)
+                     ("c3", 4096): 2 * 345934e3 + 114076e3,     # compact sampled form (materialised: ≈ 23 GB)
                      ("c5", 8192): 2 * 1.70466e9 + 1.83323e9,   # the global workspace of the grouped family (r01: 8.42 GB)
                      # profiles/r01_wide_rows_summary.md (KB per dispatch): the 1024^2 destination reads a 512^2 patch of the source
                      ("warp", 1024): 2 * 598.438e3 + 4096e3,
@@ -628,18 +628,21 @@ def main():
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
+    def launch(slv):
+        if sampled:
+            slv.solve_batch_sampled_device(stream, B, N, n_dyn, n_smp, x0.data_ptr(), U.data_ptr(), poly.data_ptr(), xpl.data_ptr(),
+                                           pose.data_ptr(), dim.data_ptr(), offs.data_ptr(), sc["sample_weight"], X.data_ptr(),
+                                           J.data_ptr(), iters.data_ptr(), status.data_ptr())
+        else:
+            slv.solve_batch_device(stream, B, N, M, x0.data_ptr(), U.data_ptr(), poly.data_ptr(), xpl.data_ptr(), pose.data_ptr(),
+                                   dim.data_ptr(), wts.data_ptr() if wts is not None else 0, X.data_ptr(), J.data_ptr(),
+                                   iters.data_ptr(), status.data_ptr())
+
     def step(k=None):
         U.copy_(U0)
         if k is not None:
             ev0[k].record()
-        if sampled:
-            solver.solve_batch_sampled_device(stream, B, N, n_dyn, n_smp, x0.data_ptr(), U.data_ptr(), poly.data_ptr(), xpl.data_ptr(),
-                                              pose.data_ptr(), dim.data_ptr(), offs.data_ptr(), sc["sample_weight"], X.data_ptr(),
-                                              J.data_ptr(), iters.data_ptr(), status.data_ptr())
-        else:
-            solver.solve_batch_device(stream, B, N, M, x0.data_ptr(), U.data_ptr(), poly.data_ptr(), xpl.data_ptr(), pose.data_ptr(),
-                                      dim.data_ptr(), wts.data_ptr() if wts is not None else 0, X.data_ptr(), J.data_ptr(),
-                                      iters.data_ptr(), status.data_ptr())
+        launch(solver)
         if k is not None:
             ev1[k].record()
         # local argmin + ONE ncclAllGather of 24 bytes per rank + the pick, all enqueued by cilqr_argmin_global_device
@@ -710,6 +713,27 @@ def main():
                                                          "note": "counts the rejected iterations the reference loop repeats and the kernel skips"}},
             "min_cost": {"J": best[0], "global_index": best[1]},
         }
+        wave_family = out["roofline"]["kernel"] == "cilqr_solve_kernel"
+        if wave_family and B > 1024 and world == 1:
+            # Batches beyond one solve per SIMD are dispatched longest-first by the pass counts of the PREVIOUS call (DESIGN.md
+            # §4.1d).  The timed steps repeat one batch, the best case for that hint; beside it the same launch on a handle
+            # created with the hint switched off — what a first call, or a batch unrelated to the one before, gets.
+            os.environ["CILQR_NO_SCHEDULE_HINT"] = "1"
+            plain = cilqr_amd.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M, device=local_rank)
+            del os.environ["CILQR_NO_SCHEDULE_HINT"]
+            c0 = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            c1 = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            for q in range(4):
+                U.copy_(U0)
+                c0[q].record()
+                launch(plain)
+                c1[q].record()
+            torch.cuda.synchronize()
+            cold_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(c0[1:], c1[1:])]))
+            plain.close()
+            out["schedule_hint"] = {"active": True, "kernel_ms_without_hint": cold_ms, "solves_per_s_without_hint": B / (cold_ms * 1e-3),
+                                    "note": "value and roofline.kernel_ms are steady state on a repeated batch: the solves are dispatched "
+                                            "longest-first by the previous call's pass counts; without_hint = same launch, dispatch in index order"}
         if args.workload == "c2" and B == 1024:  # PMC pass of the same command (profiles/r02_solver_summary.md, per launch)
             out["issue"] = {"instruction_issue_cycles": 64.4e6, "wavefront_cycles": 98.4e6, "frac": 64.4 / 98.4,
                             "valu_insts": 46.2e6, "salu_insts": 5.6e6, "lds_insts": 3.5e6,

@@ -17,4 +17,4 @@ run frame --workload frame
 run frame_1024 --workload frame --batch 1024 --steps 20 --warmup 3
 run plan --workload plan
 run plan_65536 --workload plan --batch 65536 --steps 20 --warmup 3
-for b in 2048 4096 16384 65536; do run c2_B$b --workload c2 --batch $b --steps 10 --warmup 2 --no-cpu-baseline; done
+for b in 2048 4096 8192 16384 65536; do run c2_B$b --workload c2 --batch $b --steps 10 --warmup 2 --no-cpu-baseline; done
