@@ -221,7 +221,11 @@ int cilqr_solve_batch(cilqr_handle* h, int B, int N, int M,
  * (a hipStream_t passed as void*; NULL = the HIP null stream, as everywhere in HIP).  Asynchronous: returns after launch.
  * The handle's device workspaces (obstacle table, grouped-family arrays, hand-over flags) serve ONE solve at a time: calls
  * enqueued on the same stream follow each other and are fine; solves that may overlap in time on different streams need
- * different handles. */
+ * different handles.
+ * Scheduling: a batch of more solves than the device has SIMDs is dispatched longest-first by the pass counts the solves of
+ * the PREVIOUS call on this handle had (same B, same stream: a planner solves nearly the same scenes tick after tick).  This
+ * only changes which solves start first — results are bit-identical for any order — and is switched off by
+ * CILQR_NO_SCHEDULE_HINT in the environment at cilqr_create. */
 int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
                              const double* x0, double* U, const double* poly, const double* xplan_fl,
                              const double* obs_pose, const double* obs_dim, const double* obs_weight,
