@@ -255,6 +255,16 @@ __device__ __forceinline__ void forward_controls(const FwdIn& c, const State& s,
   else u0 = fma(c.g[5], d3, fma(c.g[4], d2, fma(c.g[3], d1, fma(c.g[2], d0, c.u0 + c.g[0]))));
   u1 = fma(c.g[9], d3, fma(c.g[8], d2, fma(c.g[7], d1, fma(c.g[6], d0, c.u1 + c.g[1]))));
 }
+// The same controls (scaled form) for operands that lie in SCALAR registers (forward_smem): a vector instruction takes one
+// scalar operand, so a chain must not start from two of them — the products are summed first and the constant terms added
+// behind, one scalar each: 12 instructions and no register copies instead of 11 + 6 v_mov.
+__device__ __forceinline__ void forward_controls_scalar(const FwdIn& c, const State& s, double& u0, double& u1, double inv_half_dt) {
+  const double d0 = s.x - c.x, d1 = s.y - c.y, d2 = s.v - c.v, d3 = s.th - c.th;
+  const double t0 = fma(c.g[5], d3, fma(c.g[4], d2, fma(c.g[3], d1, c.g[2] * d0)));
+  const double t1 = fma(c.g[9], d3, fma(c.g[8], d2, fma(c.g[7], d1, c.g[6] * d0)));
+  u0 = fma(t0 + c.g[0], inv_half_dt, c.u0);
+  u1 = (t1 + c.g[1]) + c.u1;
+}
 template <bool SCALED = false>
 __device__ __forceinline__ void forward_step(const FwdConst& k, const FwdIn& c, State& s, double& max_turn, double& u0, double& u1,
                                              double inv_half_dt = 1.0) {

@@ -572,7 +572,7 @@ __device__ __forceinline__ bool forward_smem(const KParams& kp, int N, const dou
     f_swait(r);
     f_sunpack(c, r);
     double u0, u1;
-    forward_controls<true>(c, s, u0, u1, ihd);
+    forward_controls_scalar(c, s, u0, u1, ihd);
     f_sload_next(r, recp(i + 1));
     Un[2 * i] = u0; Un[2 * i + 1] = u1;
     const double delta = dyn_pose_loop(k, s, u0, u1, max_turn);
