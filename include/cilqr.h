@@ -319,18 +319,37 @@ int cilqr_create_multi(const cilqr_params* p, int max_batch_per_device, int max_
 int cilqr_multi_destroy(cilqr_multi* m);
 int cilqr_multi_device_count(const cilqr_multi* m);
 cilqr_handle* cilqr_multi_handle(cilqr_multi* m, int i); /* device i's handle, for the *_device entry points */
-/* cilqr_solve_batch over all devices: host buffers as there, solves sharded contiguously (device d owns
- * [d·ceil(B/n), (d+1)·ceil(B/n)) ∩ [0, B)), every device's copies and kernels enqueued before any wait, followed by the exchange
- * step; best_index / best_J (may be NULL) receive the global min-cost pick. */
+/* The shard of a batch of B solves that device (or rank) `shard` of `n_shards` owns: contiguous by scene and balanced — the first
+ * B mod n shards own one solve more; shards may be empty when B < n.  Host arithmetic only (no device needed): the rule
+ * cilqr_multi_solve_batch applies, exported so that a one-process-per-GPU host shards the same way. */
+int cilqr_shard_range(int B, int n_shards, int shard, int* first, int* count);
+/* cilqr_solve_batch over all devices: host buffers as there, solves sharded by cilqr_shard_range, followed by the exchange
+ * step; best_index / best_J (may be NULL) receive the global min-cost pick.  Each device's shard is enqueued (copies in,
+ * kernels, copies out, the shard's argmin) by its own host thread, so the devices overlap whatever the caller's memory is:
+ * from pageable buffers a hipMemcpyAsync is a synchronous copy, and one thread walking the devices would serialise them; with
+ * buffers from cilqr_host_alloc the copies are true DMA transfers on every device's own stream.  On any failure every
+ * device's stream is drained before the error is returned — no copy into caller memory is left in flight — and the handles
+ * are free for the next call.
+ * A device list that names one device several times (shards sharing a GPU: how a one-GPU box rehearses the n-shard path) gets
+ * no RCCL communicator — RCCL cannot span a device twice — and gathers the 24-byte records with device copies ordered by
+ * events instead; cilqr_multi_uses_rccl tells which. */
 int cilqr_multi_solve_batch(cilqr_multi* m, int B, int N, int M, const double* x0, double* U, const double* poly,
                             const double* xplan_fl, const double* obs_pose, const double* obs_dim, const double* obs_weight,
                             double* X_out, double* J_out, int32_t* iters_out, int32_t* status_out, uint32_t flags,
                             int64_t* best_index, double* best_J);
+int cilqr_multi_uses_rccl(const cilqr_multi* m); /* 1: distinct devices, exchange by ncclAllGather; 0: shards share a device */
+/* Test hook: the nth_call-th host-buffer solve enqueued on `h` from now on fails AFTER its input copies were enqueued
+ * (nth_call = 1: the next one; 0 switches the hook off) — the error path of cilqr_solve_batch / cilqr_multi_solve_batch with
+ * asynchronous copies in flight. */
+int cilqr_debug_fail_enqueue(cilqr_handle* h, int nth_call);
 
 /* Diagnostics (the reference's only tracing is std::chrono around run_step, I/ilqr_uncertainty_node.cpp:117-124): while
- * dev_buf != NULL, solves run a separately compiled, stamped instantiation of the kernel that writes, per solve, 8
- * uint64 shader-clock totals {prologue, linearise, Riccati, forward, epilogue, #linearise, #Riccati, total} to
- * dev_buf[B][8] (device memory owned by the caller).  NULL restores the production kernel.  Never use it when timing. */
+ * dev_buf != NULL, solves run a separately compiled, stamped instantiation of the kernel that writes, per solve, 16
+ * uint64 to dev_buf[B][16] (device memory owned by the caller): shader-clock totals {prologue, linearise, Riccati, forward,
+ * epilogue, #linearise, #Riccati, total}, then (one-wavefront-per-solve family; 0 elsewhere) totals inside the linearisation
+ * {cos/sin columns, closest path sample, cost derivatives, record stores, cost reduction} and inside the Riccati steps
+ * {products up to Q_uu in scalar registers, determinant and reciprocal, rest of the step}.  NULL restores the production
+ * kernel.  Never use it when timing. */
 int cilqr_set_diag_buffer(cilqr_handle* h, uint64_t* dev_buf);
 
 /* Measurement hook: while dev_buf != NULL every solve also writes the number of backward + forward passes it actually

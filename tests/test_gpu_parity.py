@@ -1367,24 +1367,103 @@ def test_argmin_global_device_single_rank_and_rccl_world1(cilqr, solver):
         s.close()
 
 
-def test_cpp_host_shards_over_all_devices(cilqr, tmp_path):
-    """tests/cpp/multi_device.cpp: a C++ host with no Python in it runs one batch over hipGetDeviceCount() devices through
-    cilqr_create_multi / cilqr_multi_solve_batch (RCCL exchange inside) — bit-equal to the single-handle batch and pick."""
-    import json
+def _build_multi_device(tmp_path):
     import os
     import subprocess
     from conftest import PKG, ROOT
     exe = str(tmp_path / "multi_device")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-o", exe,
-                    os.path.join(ROOT, "tests", "cpp", "multi_device.cpp"), "-L" + os.path.join(PKG, "lib"), "-lcilqr_hip",
-                    "-Wl,-rpath," + os.path.join(PKG, "lib")], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", "-o", exe,
+                    os.path.join(ROOT, "tests", "cpp", "multi_device.cpp"), "-L" + os.path.join(PKG, "lib"), "-lcilqr_hip", "-L/opt/rocm/lib",
+                    "-lamdhip64", "-Wl,-rpath," + os.path.join(PKG, "lib"), "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return exe
+
+
+def _run_json(cmd, env=None):
+    import json
+    import subprocess
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]  # RCCL may print a version banner before it
+    assert r.returncode == 0 and lines, r.stdout + r.stderr
+    return json.loads(lines[-1])
+
+
+def test_cpp_host_shards_over_all_devices(cilqr, tmp_path):
+    """tests/cpp/multi_device.cpp: a C++ host with no Python in it runs one batch over n = 1 .. cilqr_device_count() devices
+    through cilqr_create_multi / cilqr_multi_solve_batch (RCCL exchange inside) — bit-equal to the single-handle batch and pick.
+    Small batches take the packed staging path, B = 1500 the array-by-array copies, from pageable and from pinned memory."""
+    exe = _build_multi_device(tmp_path)
     n = cilqr.lib().cilqr_device_count()
     assert n >= 1
-    for B in (37, 5):
-        r = subprocess.run([exe, str(B)], capture_output=True, text=True)
-        assert r.returncode == 0, r.stdout + r.stderr
-        out = json.loads(r.stdout.strip().splitlines()[-1])  # RCCL may print a version banner before it
-        assert out["bit_equal"] and out["devices"] == n and out["best_single"] == out["best_multi"]
+    for args in (["--B", "37"], ["--B", "5"], ["--B", "1500"], ["--B", "1500", "--pinned"]):
+        out = _run_json([exe] + args)
+        assert out["bit_equal"] and out["devices"] == n and out["cases"] == 3 * n and out["rccl_cases"] == n, out
+
+
+def test_cpp_host_shard_arithmetic_with_several_shards_on_one_device(cilqr, tmp_path):
+    """The n-shard path of cilqr_multi_solve_batch (cilqr_shard_range, per-device host threads, the gather, the pick) with
+    n = 2, 3, 8 shards on device 0 — ragged batches, batches smaller than the shard count (empty shards) — bit-equal to one
+    handle.  (Shards sharing a device exchange their records by device copies; distinct devices use RCCL: the test above.)"""
+    exe = _build_multi_device(tmp_path)
+    for shards, B in ((2, 37), (3, 37), (8, 5), (3, 2), (2, 1), (8, 1100), (3, 1500)):
+        out = _run_json([exe, "--shards", str(shards), "--B", str(B)])
+        assert out["bit_equal"] and out["cases"] == 3 and out["rccl_cases"] == 0, out
+
+
+def test_cpp_host_failure_with_copies_in_flight_leaves_nothing_behind(cilqr, tmp_path):
+    """cilqr_debug_fail_enqueue on one shard's handle: the call fails AFTER other shards' (and its own) asynchronous copies were
+    enqueued; it must report the error, drain every stream, and the next call on the same handles must succeed bit-equal."""
+    exe = _build_multi_device(tmp_path)
+    for shards, d, extra in ((3, 1, []), (2, 0, []), (3, 2, ["--pinned"]), (2, 1, ["--B", "1500"])):
+        out = _run_json([exe, "--shards", str(shards), "--fail", str(d)] + extra)
+        assert out["bit_equal"] and out["forced_failures"] == 1 and out["cases"] == 2, out
+    out = _run_json([exe, "--fail", "0"])  # the one-device RCCL configuration
+    assert out["bit_equal"] and out["forced_failures"] >= 1, out
+
+
+def test_cpp_host_one_process_per_gpu_route(cilqr, tmp_path):
+    """The other host model from a C++ process: RANK / WORLD_SIZE in the environment, RCCL id through a file
+    (cilqr_comm_unique_id → cilqr_comm_init_rank), the shard by cilqr_shard_range, cilqr_argmin_global_device.  World size =
+    the devices present (1 on the test box; the same command line runs per rank on a node)."""
+    import os
+    import subprocess
+    exe = _build_multi_device(tmp_path)
+    n = cilqr.lib().cilqr_device_count()
+    idfile = str(tmp_path / "comm_id")
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(n), LOCAL_RANK=str(r), CILQR_ID_FILE=idfile)
+        procs.append(subprocess.Popen([exe, "--B", "41"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    import json
+    for pr in procs:
+        so, se = pr.communicate(timeout=300)
+        lines = [ln for ln in so.strip().splitlines() if ln.startswith("{")]
+        assert pr.returncode == 0 and lines, so + se
+        out = json.loads(lines[-1])
+        assert out["bit_equal"] and out["world"] == n and out["best_single"] == out["best_global"], out
+
+
+def test_host_call_failure_drains_and_frees_the_handle(cilqr, oracle):
+    """cilqr_solve_batch with a forced failure after its input copies were enqueued (pinned buffers: true asynchronous DMA):
+    error reported, the handle usable at once, the next call's results equal the oracle's."""
+    from cilqr_amd import scenes
+    N, M, B = 50, 4, 1200  # beyond the 1 MiB staging buffer: array-by-array copies straight from the caller's memory
+    p = cilqr.default_params(N)
+    sc = scenes.make_c2(B, p)
+    s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M)
+    pin = {k: cilqr.pinned_copy(sc[k]) for k in ("x0", "U", "poly", "xplan_fl", "obs_pose", "obs_dim")}
+    out = dict(U=cilqr.pinned_empty((B, 2 * N)), X=cilqr.pinned_empty((B, 4 * (N + 1))), J=cilqr.pinned_empty((B,)),
+               iters=cilqr.pinned_empty((B,), np.int32), status=cilqr.pinned_empty((B,), np.int32))
+    out["U"][...] = sc["U"]
+    cilqr._check(cilqr.lib().cilqr_debug_fail_enqueue(s._h, 1))
+    with pytest.raises(cilqr.CilqrError) as e:
+        s.solve_batch(N, pin["x0"], pin["U"], pin["poly"], pin["xplan_fl"], pin["obs_pose"], pin["obs_dim"], out=out)
+    assert "forced failure" in str(e.value)
+    out["U"][...] = sc["U"]
+    got = s.solve_batch(N, pin["x0"], pin["U"], pin["poly"], pin["xplan_fl"], pin["obs_pose"], pin["obs_dim"], out=out)
+    ns = 64
+    want = oracle.solve_batch(oracle.default_params(N), N, M, *[np.ascontiguousarray(sc[k][:ns]) for k in ("x0", "U", "poly", "xplan_fl", "obs_pose", "obs_dim")], None, threads=16)
+    assert np.max(np.abs(got["U"][:ns] - want["U"])) <= 1e-9 and np.array_equal(got["iters"][:ns], want["iters"])
+    s.close()
 
 
 # ---- costmap-lookup uncertainty cost (SURVEY §8f-3; semantics defined by include/cilqr.h, PARITY UNPINNED) -------------------

@@ -80,3 +80,26 @@ def test_rank_shards_are_disjoint_seeds(cilqr):
     c = scenes.make_static(8, 50, 4, p, scenes.SEED0 + 2 + 1000)
     assert np.array_equal(a["x0"], b["x0"]) and np.array_equal(a["obs_pose"], b["obs_pose"])
     assert not np.array_equal(a["x0"], c["x0"])
+
+
+def test_shard_rule_covers_the_batch_contiguously_and_evenly(cilqr):
+    """`cilqr_shard_range` (host arithmetic of cilqr_multi_solve_batch, no device needed): for every device count and the
+    awkward batch sizes — empty, smaller than the device count, one off a multiple — the shards are contiguous, disjoint, cover
+    [0, B) in device order and differ by at most one solve."""
+    for n in (1, 2, 3, 8):
+        sizes = {0, 1, n - 1, n, n + 1}
+        for per in (1, 5, 128, 8192):
+            sizes |= {n * per - 1, n * per, n * per + 1}
+        for B in sorted(b for b in sizes if b >= 0):
+            shards = [cilqr.shard_range(B, n, d) for d in range(n)]
+            nxt = 0
+            for first, count in shards:
+                assert first == nxt and count >= 0, (n, B, shards)
+                nxt = first + count
+            assert nxt == B
+            counts = [c for _, c in shards]
+            assert max(counts) - min(counts) <= 1 and counts == sorted(counts, reverse=True), (n, B, counts)
+            assert max(counts) == -(-B // n)  # what cilqr_create_multi's max_batch_per_device must hold
+    for bad in ((-1, 2, 0), (4, 0, 0), (4, 2, 2), (4, 2, -1)):
+        with pytest.raises(cilqr.CilqrError):
+            cilqr.shard_range(*bad)

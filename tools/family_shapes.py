@@ -33,7 +33,9 @@ def run(N, M, B, force):
         best = min(best, e0.elapsed_time(e1))
     return best, float(it.float().mean())
 
-shapes = [(30, 2), (50, 0), (50, 4), (50, 8), (50, 12), (80, 4), (80, 8), (80, 16), (120, 4)]
+shapes = [(30, 2), (50, 0), (50, 4), (50, 8), (50, 12), (80, 4), (80, 8), (80, 16), (100, 4), (120, 4), (120, 16), (160, 4)]
+if os.environ.get("SHAPES"):
+    shapes = [tuple(int(v) for v in q.split("x")) for q in os.environ["SHAPES"].split(",")]
 for N, M in shapes:
     for B in (2048, 4096, 8192, 16384):
         a, ia = run(N, M, B, 0)

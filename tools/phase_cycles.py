@@ -15,7 +15,7 @@ x0, U, poly, xpl = dv(sc["x0"]), dv(sc["U"]), dv(sc["poly"]), dv(sc["xplan_fl"])
 pose, dim = (dv(sc["obs_pose"]), dv(sc["obs_dim"])) if M else (None, None)
 X = torch.zeros(B, 4 * (N + 1), dtype=torch.float64, device="cuda"); J = torch.zeros(B, dtype=torch.float64, device="cuda")
 it = torch.zeros(B, dtype=torch.int32, device="cuda"); st = torch.zeros(B, dtype=torch.int32, device="cuda")
-diag = torch.zeros(B, 8, dtype=torch.int64, device="cuda")
+diag = torch.zeros(B, 16, dtype=torch.int64, device="cuda")
 s.set_diag_buffer(diag.data_ptr())
 U0 = U.clone()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -43,4 +43,10 @@ m = nR > 0
 print("R per call: %.0f -> %.0f per step" % ((d[m, 2] / nR[m]).mean(), (d[m, 2] / nR[m]).mean() / N))
 print("F per call: %.0f -> %.0f per step" % ((d[m, 3] / nR[m]).mean(), (d[m, 3] / nR[m]).mean() / N))
 w = int(np.argmax(d[:, 7]))
-print("slowest solve %d: pro %d L %d R %d F %d epi %d nL %d nR %d total %d" % ((w,) + tuple(int(v) for v in d[w])))
+print("slowest solve %d: pro %d L %d R %d F %d epi %d nL %d nR %d total %d" % ((w,) + tuple(int(v) for v in d[w][:8])))
+if d[:, 8:].sum() > 0:  # sub-phase stamps (one-wavefront-per-solve family)
+    names = ["cos/sin columns", "closest sample (+ forward-record stores)", "cost derivatives (lin_step)", "record stores (+ map term)", "cost reduction"]
+    print("inside L, ticks per call:  " + "  ".join("%s %.0f" % (n, (d[:, 8 + i] / nL).mean()) for i, n in enumerate(names)))
+    names = ["P, Db, Da + readlanes", "determinant + reciprocal", "Dk, H, Dv, copies, stores"]
+    print("inside R, ticks per step:  " + "  ".join("%s %.0f" % (n, (d[m, 13 + i] / nR[m]).mean() / N) for i, n in enumerate(names))
+          + "   (four s_memtime and one s_waitcnt lgkmcnt(0) per step: compare the sum with the unstamped R per step of a DIAG-free run)")

@@ -15,7 +15,7 @@ x0, U, poly, xpl = dv(sc["x0"]), dv(sc["U"]), dv(sc["poly"]), dv(sc["xplan_fl"])
 pose, dim, off = dv(sc["nom_pose"]), dv(sc["nom_dim"]), dv(sc["offsets"])
 X = torch.zeros(B, 4 * (N + 1), dtype=torch.float64, device="cuda"); J = torch.zeros(B, dtype=torch.float64, device="cuda")
 it = torch.zeros(B, dtype=torch.int32, device="cuda"); st = torch.zeros(B, dtype=torch.int32, device="cuda")
-diag = torch.zeros(B, 8, dtype=torch.int64, device="cuda")
+diag = torch.zeros(B, 16, dtype=torch.int64, device="cuda")
 s.set_diag_buffer(diag.data_ptr())
 s.solve_batch_sampled_device(0, B, N, 8, 32, x0.data_ptr(), U.data_ptr(), poly.data_ptr(), xpl.data_ptr(), pose.data_ptr(),
                              dim.data_ptr(), off.data_ptr(), 1.0 / 32, X.data_ptr(), J.data_ptr(), it.data_ptr(), st.data_ptr())

@@ -14,9 +14,18 @@ for w in c2 c3 c5; do
     echo "pmc $w $c done"
   done
 done
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/c2_pmc_SQ -o c2 -- python3 $ROOT/bench.py --workload c2 --steps 4 --warmup 1 --no-cpu-baseline > $OUT/c2_pmc_SQ.log 2>&1
+# issue and memory-wait counters, and the L2's hit / miss counts, for every configuration (8 SQ slots / 4 TCC slots per pass)
+for w in c2 c3 c5; do
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/${w}_pmc_SQ -o ${w} -- python3 $ROOT/bench.py --workload $w --steps 4 --warmup 1 --no-cpu-baseline > $OUT/${w}_pmc_SQ.log 2>&1
+  rocprofv3 --pmc SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_F64 --output-format csv -d $OUT/${w}_pmc_SQ2 -o ${w} -- python3 $ROOT/bench.py --workload $w --steps 4 --warmup 1 --no-cpu-baseline > $OUT/${w}_pmc_SQ2.log 2>&1 || echo "SQ2 pass failed for $w (a counter name?)"
+  rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/${w}_pmc_TCC -o ${w} -- python3 $ROOT/bench.py --workload $w --steps 4 --warmup 1 --no-cpu-baseline > $OUT/${w}_pmc_TCC.log 2>&1 || echo "TCC pass failed for $w"
+  echo "counters $w done"
+done
 cd $ROOT
-python3 tools/prof_summary.py "${PROF_TITLE:-r02 — solver configurations 2, 3 (compact sampled obstacles), 5: bench.py --workload cN --no-cpu-baseline}" \
+python3 tools/prof_summary.py "${PROF_TITLE:-r03 — solver configurations 2, 3 (compact sampled obstacles), 5: bench.py --workload cN --no-cpu-baseline}" \
   $OUT/c2_stats $OUT/c3_stats $OUT/c5_stats $OUT/c2_pmc_FETCH_SIZE $OUT/c2_pmc_WRITE_SIZE $OUT/c3_pmc_FETCH_SIZE $OUT/c3_pmc_WRITE_SIZE \
-  $OUT/c5_pmc_FETCH_SIZE $OUT/c5_pmc_WRITE_SIZE $OUT/c2_pmc_SQ > $ROOT/gpurun_out/prof_solver_summary.md
+  $OUT/c5_pmc_FETCH_SIZE $OUT/c5_pmc_WRITE_SIZE $OUT/c2_pmc_SQ $OUT/c3_pmc_SQ $OUT/c5_pmc_SQ $OUT/c2_pmc_SQ2 $OUT/c3_pmc_SQ2 $OUT/c5_pmc_SQ2 \
+  $OUT/c2_pmc_TCC $OUT/c3_pmc_TCC $OUT/c5_pmc_TCC > $ROOT/gpurun_out/prof_solver_summary.md
+# keep only the small files that travel back (csv of stats and counters), not the raw traces
+find $OUT -name "*.db" -delete 2>/dev/null || true
 du -sh $OUT

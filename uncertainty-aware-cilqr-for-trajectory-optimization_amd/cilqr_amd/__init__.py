@@ -26,6 +26,7 @@ ABI_SYMBOLS = (
     "cilqr_set_uncertainty_map", "cilqr_set_uncertainty_map_device", "cilqr_clear_uncertainty_map", "cilqr_debug_uncertainty_cost",
     "cilqr_comm_unique_id", "cilqr_comm_init_rank", "cilqr_comm_destroy", "cilqr_comm_size", "cilqr_argmin_global_device", "cilqr_debug_select",
     "cilqr_create_multi", "cilqr_multi_destroy", "cilqr_multi_device_count", "cilqr_multi_handle", "cilqr_multi_solve_batch",
+    "cilqr_shard_range", "cilqr_multi_uses_rccl", "cilqr_debug_fail_enqueue",
 )
 
 _dp = C.POINTER(C.c_double)
@@ -91,6 +92,13 @@ def comm_unique_id():
     buf = (C.c_char * COMM_ID_BYTES)()
     _check(lib().cilqr_comm_unique_id(buf))
     return bytes(buf.raw)
+
+
+def shard_range(B, n_shards, shard):
+    """`cilqr_shard_range`: (first, count) of the contiguous, balanced shard a device / rank owns (host arithmetic only)."""
+    first, count = C.c_int(), C.c_int()
+    _check(lib().cilqr_shard_range(int(B), int(n_shards), int(shard), C.byref(first), C.byref(count)))
+    return first.value, count.value
 
 
 def pinned_empty(shape, dtype=np.float64):

@@ -422,8 +422,8 @@ int cilqr_solve_batch(cilqr_handle* h, int B, int N, int M, const double* x0, do
   if (!x0 || !U || !poly || !xplan_fl || !X_out) return fail(CILQR_ERR_ARG, "cilqr_solve_batch: null required pointer");
   if (M > 0 && (!obs_pose || !obs_dim)) return fail(CILQR_ERR_ARG, "cilqr_solve_batch: M > 0 but obstacle tables are null");
   cilqr::HostBatch q{B, N, M, 0, x0, U, poly, xplan_fl, obs_pose, obs_dim, obs_weight, nullptr, 0.0, X_out, J_out, iters_out, status_out, flags};
-  rc = cilqr::host_solve_enqueue(h, q);
-  if (rc) { h->pending.active = false; return rc; }
+  rc = cilqr::host_solve_enqueue(h, q);  // (on failure: stream drained, handle free again)
+  if (rc) return rc;
   return cilqr::host_solve_finish(h);
 }
 
@@ -472,8 +472,8 @@ int cilqr_solve_batch_sampled(cilqr_handle* h, int B, int N, int n_obs, int n_sa
     return fail(CILQR_ERR_ARG, "cilqr_solve_batch_sampled: null required pointer");
   cilqr::HostBatch q{B, N, n_obs, n_samples, x0, U, poly, xplan_fl, nom_pose, nom_dim, nullptr, sample_offset, sample_weight, X_out, J_out,
                      iters_out, status_out, flags};
-  rc = cilqr::host_solve_enqueue(h, q);
-  if (rc) { h->pending.active = false; return rc; }
+  rc = cilqr::host_solve_enqueue(h, q);  // (on failure: stream drained, handle free again)
+  if (rc) return rc;
   return cilqr::host_solve_finish(h);
 }
 

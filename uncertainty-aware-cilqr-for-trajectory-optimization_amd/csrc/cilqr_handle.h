@@ -60,6 +60,7 @@ struct cilqr_handle {
   char* stage;
   size_t stage_cap;
   cilqr::PendingOut pending;
+  int debug_fail_enqueue;  // test hook: the n-th host-buffer enqueue from now fails after its input copies (0: off)
   double* d_J;  // the costs of the last host-buffer call, inside the arena
   void* scratch[cilqr::SCR_SLOTS];
   size_t scratch_cap[cilqr::SCR_SLOTS];

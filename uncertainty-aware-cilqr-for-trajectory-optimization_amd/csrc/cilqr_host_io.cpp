@@ -42,8 +42,26 @@ IoLayout io_layout(size_t B, size_t N, size_t M, bool weights, size_t n_samples)
   return L;
 }
 
+namespace {
+int enqueue_steps(cilqr_handle* h, const HostBatch& q);
+}
+
+// Enqueues a call; on any failure nothing is left behind: the stream is drained first — asynchronous copies to or from the
+// CALLER's memory may already be in flight when a later step fails — and the handle is free for the next call.
 int host_solve_enqueue(cilqr_handle* h, const HostBatch& q) {
   if (h->pending.active) return fail(CILQR_ERR_ARG, "a host-buffer solve is already in flight on this handle");
+  const int rc = enqueue_steps(h, q);
+  if (rc != CILQR_OK) {
+    const std::string msg = g_last_error;
+    (void)hipStreamSynchronize(h->stream);
+    h->pending.active = false;
+    g_last_error = msg;
+  }
+  return rc;
+}
+
+namespace {
+int enqueue_steps(cilqr_handle* h, const HostBatch& q) {
   const bool sampled = q.n_samples > 0;
   const size_t B = q.B, N = q.N, M = q.M;
   const bool have_w = !sampled && q.obs_weight && M > 0;
@@ -81,6 +99,8 @@ int host_solve_enqueue(cilqr_handle* h, const HostBatch& q) {
     }
     HIP_TRY(hipMemcpyAsync(dv + L.U, q.U, n_U, hipMemcpyHostToDevice, s));
   }
+  if (h->debug_fail_enqueue > 0 && --h->debug_fail_enqueue == 0)  // test hook (cilqr_debug_fail_enqueue): fail with the copies in flight
+    return fail(CILQR_ERR_HIP, "forced failure after the input copies were enqueued (cilqr_debug_fail_enqueue)");
   double* dU = (double*)(dv + L.U);
   double* dX = (double*)(dv + L.X);
   double* dJ = (double*)(dv + L.J);
@@ -113,6 +133,7 @@ int host_solve_enqueue(cilqr_handle* h, const HostBatch& q) {
   h->pending.q = q;
   return CILQR_OK;
 }
+}  // namespace
 
 int host_solve_finish(cilqr_handle* h) {
   if (!h->pending.active) return CILQR_OK;
@@ -162,6 +183,12 @@ void* cilqr_host_alloc(size_t bytes) {
     return nullptr;
   }
   return p;
+}
+
+int cilqr_debug_fail_enqueue(cilqr_handle* h, int nth_call) {
+  if (!h || nth_call < 0) return fail(CILQR_ERR_ARG, "cilqr_debug_fail_enqueue: bad argument");
+  h->debug_fail_enqueue = nth_call;
+  return CILQR_OK;
 }
 
 int cilqr_host_free(void* p) {

@@ -39,6 +39,8 @@ struct UncArgs {
   double q1, q2, scale;              // barrier constants; scale = w_uncertainty / (nl*nw)
 };
 
+constexpr int DIAG_SLOTS = 16;  // uint64 per solve in the diagnostic buffer (include/cilqr.h, cilqr_set_diag_buffer)
+
 struct SolveArgs {
   const double* x0;
   double* U;
@@ -57,7 +59,7 @@ struct SolveArgs {
   double* obs_tab;      // workspace: [B][M][N][6] (sampled: [B][M][N][8])
   double* fwd;          // workspace of the one-wavefront-per-solve family: [B][N + 1][16] forward-pass records (cilqr_solve.hip)
   int32_t* redo;        // workspace: [B] hand-over flags from the fast kernel to the general kernel
-  unsigned long long* diag;  // null, or [B][8] phase cycle totals (diagnostic instantiation)
+  unsigned long long* diag;  // null, or [B][DIAG_SLOTS] phase cycle totals (diagnostic instantiation)
   int32_t* passes;      // null, or [B]: backward+forward passes each solve actually executed (cilqr_set_pass_count_buffer)
   // Dispatch order of the one-wavefront-per-solve family for batches beyond one solve per SIMD (cilqr_api.cpp, schedule hint):
   const int32_t* order;  // null, or [B]: workgroup i runs solve order[i] (a permutation: longest solves of the previous call first)

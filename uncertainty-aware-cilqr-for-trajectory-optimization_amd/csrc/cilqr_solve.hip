@@ -213,13 +213,38 @@ struct SampledSource {
   }
 };
 
+// Shader-clock stamp of the diagnostic instantiation, ordered by the compiler behind the value it names (the hardware issues in
+// order: a stamp is taken when everything before it has ISSUED, and an instruction that needs an unfinished result stalls there).
+__device__ __forceinline__ unsigned long long stamp_after(double v) {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(v) : "memory");
+  return t;
+}
+// Stamps inside a step of the serial phases: requested without a wait (a wait per stamp costs the step ≈ 70 ticks each and the
+// prefetched operand reads their cover), collected behind ONE s_waitcnt at the end of the step.
+__device__ __forceinline__ void stamp_request(unsigned long long& t, double v) {
+  asm volatile("s_memtime %0" : "=s"(t) : "v"(v) : "memory");
+}
+__device__ __forceinline__ void stamps_collect(unsigned long long& a, unsigned long long& b, unsigned long long& c, unsigned long long& d) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+s"(d) : : "memory");
+}
+#define CILQR_SUB(slot, val)                          \
+  if (DIAG) {                                         \
+    const unsigned long long now_ = stamp_after(val); \
+    sub[slot] += now_ - sub_t;                        \
+    sub_t = now_;                                     \
+  }
+
 // Phase L.  Returns this lane's partial of J over its timesteps.  M = number of obstacle entries per step.
-// RECW: doubles per stored record.
-template <int RECW, bool FSMEM, typename Source>
+// RECW: doubles per stored record.  DIAG: sub[0..3] += ticks of {cos/sin columns, closest sample, cost derivatives, stores}.
+template <int RECW, bool FSMEM, bool DIAG, typename Source>
 __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int lane, const double* samp, int S,
                                             const SampleGrid& grid, double* X, const double* U, double* rec,
-                                            const Source& src, const UncArgs* unc, UncPose upose, int ub, double* fwd) {
+                                            const Source& src, const UncArgs* unc, UncPose upose, int ub, double* fwd,
+                                            unsigned long long* sub) {
   double Jpart = 0.0;
+  unsigned long long sub_t = 0;
+  if (DIAG) sub_t = stamp_after(0.0);
   if (FSMEM) {
     // Scalar-path forward pass (forward_smem): it stores {x, y, v, theta} only — its cos/sin store was the last LDS instruction of a step
     // and the next step's wait paid its latency (34 ticks per step, 50 steps per pass) — so the cos/sin columns are filled here,
@@ -231,6 +256,7 @@ __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int
     }
     __syncthreads();
   }
+  CILQR_SUB(0, Jpart)
   for (int t = lane; t < N; t += WAVE) {
     const double* xr = X + t * XR;
     const double* xn = X + (t + 1) * XR;
@@ -242,9 +268,11 @@ __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int
       q[2] = make_double2(U[2 * t], U[2 * t + 1]);
     }
     const int cs = closest_sample(S, grid, px, py, LdsSamples{samp, grid.xf, grid.dxs});
+    CILQR_SUB(1, (double)cs)
     Rec c;
     Jpart += lin_step<true, Source::kPaired>(kp, px, py, xr[2], xr[4], xr[5], U[2 * t], U[2 * t + 1], xn[2], xn[4], xn[5], fma(grid.dxs, (double)cs, grid.xf),
                       samp[cs], M, src.at(t), c);
+    CILQR_SUB(2, c.lx0 + c.lu0 + c.ga + Jpart)
     double* r = rec + t * RECW;
     r[0] = c.lx0; r[1] = c.lx1; r[2] = c.lx2; r[3] = c.l00; r[4] = c.l01; r[5] = c.l11;
     r[7] = c.lu1; r[9] = c.luu1;
@@ -266,6 +294,7 @@ __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int
       r[0] = lx0; r[1] = lx1; r[3] = h00; r[4] = h01; r[5] = h11;
     }
   }
+  CILQR_SUB(3, Jpart)
   return Jpart;
 }
 
@@ -404,8 +433,10 @@ __device__ __forceinline__ void mfma_place(const double*& ptr, int& stride, int 
   stride = slot >= 0 ? 2 * RECF : 0;
 }
 
-template <bool FSMEM>
-__device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* kK, double* fwd, const double* cst, double inv_half_dt, double lamb_in) {
+// DIAG: sub[5..7] += ticks of {the three products up to a, b, d in scalar registers; determinant and reciprocal; the rest of the step}.
+template <bool FSMEM, bool DIAG>
+__device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* kK, double* fwd, const double* cst, double inv_half_dt, double lamb_in,
+                                             unsigned long long* sub) {
   constexpr int C0 = -1, C1 = -2, CDT = -3, CW = -4, C2 = -5;
   const int lane = threadIdx.x;
   const int e = ((lane >> 4) << 2) | (lane & 3);  // 4·r + c of this lane's entry
@@ -450,16 +481,20 @@ __device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* k
   int signs_v = 0, signs_s = 0;  // (one word in a vector register for det0, one in a scalar register for a and d: no transfers)
   double det0 = 0.0;
   auto step = [&](const MfmaOperands& o) {
+    unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (DIAG) stamp_request(s0, V);
     const double P = CILQR_MFMA(V, o.AB, vc);
     const double Db = CILQR_MFMA(o.BB, P, o.Cb);
     const double Da = CILQR_MFMA(o.AA, P, o.Ca);
     const double a = readlane_f64(Db, 4), b = readlane_f64(Db, 5), d = readlane_f64(Db, 21);
+    if (DIAG) stamp_request(s1, a + b + d);
     const double bb = b * b;
     det0 = fma(a, d, -bb);
     signs_v |= __double2hiint(det0);
     signs_s |= __double2hiint(a) | __double2hiint(d);
     const double ar = a + lamb0, dr = d + lamb;
     const double nr = -rcp_newton(fma(ar, dr, -bb));
+    if (DIAG) stamp_request(s2, nr);
     const double adj = fma(ar, m11, fma(-b, m01, dr * m00));
     const double Dk = CILQR_MFMA(adj, Db, 0.0) * nr;
     const double H0 = fma(lamb_row, Dk, Db);
@@ -475,6 +510,11 @@ __device__ __forceinline__ bool riccati_mfma(int N, const double* rec, double* k
     } else {
       *gp = Dk;
       gp -= RECF;
+    }
+    if (DIAG) {
+      stamp_request(s3, V);
+      stamps_collect(s0, s1, s2, s3);
+      sub[5] += s1 - s0; sub[6] += s2 - s1; sub[7] += s3 - s2;
     }
   };
   // two steps per trip: the lower step's operands are read while the upper one computes, the next trip's upper operands while
@@ -668,6 +708,7 @@ __device__ __forceinline__ bool rollout_fast(const KParams& kp, int N, const dou
 template <bool DIAG, int TAB, bool GENERAL, bool UNC>
 __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   unsigned long long tk0 = 0, tk = 0, c_pro = 0, c_L = 0, c_R = 0, c_F = 0, n_L = 0, n_R = 0;
+  unsigned long long sub[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // DIAG: ticks inside phases L (0-4) and R (5-7)
   if (DIAG) tk0 = tk = __builtin_readcyclecounter();
 #define CILQR_STAMP(acc)                                 \
   if (DIAG) {                                            \
@@ -843,10 +884,13 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
       double part;
       const KParams kpl = phase_params();  // phase-local read of the parameter block (cilqr_device.hpp)
       const UncArgs* unc = has_unc ? &phase_args().unc : nullptr;  // uniform: a map is set (cilqr_set_uncertainty_map*)
-      if (TAB == 2) part = linearize<RECW, FSMEM>(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, SampledSource{tab, off, rmax, Xc, N, a.n_samples, M, a.samp_w, kpl.ego_front, kpl.ego_rear,
-                                                     sqrt(1.0 + 64.0 / kpl.q2_front), sqrt(1.0 + 64.0 / kpl.q2_rear)}, unc, upose, b, fwd);
-      else part = linearize<RECW, FSMEM>(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, TabSource<TAB == 0>{tab, wts, N, kpl.w_obstacle}, unc, upose, b, fwd);
+      if (TAB == 2) part = linearize<RECW, FSMEM, DIAG>(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, SampledSource{tab, off, rmax, Xc, N, a.n_samples, M, a.samp_w, kpl.ego_front, kpl.ego_rear,
+                                                     sqrt(1.0 + 64.0 / kpl.q2_front), sqrt(1.0 + 64.0 / kpl.q2_rear)}, unc, upose, b, fwd, sub);
+      else part = linearize<RECW, FSMEM, DIAG>(kpl, N, n_entries, lane, samp, S, grid, Xc, Uc, rec, TabSource<TAB == 0>{tab, wts, N, kpl.w_obstacle}, unc, upose, b, fwd, sub);
+      unsigned long long sub_t = 0;
+      if (DIAG) sub_t = stamp_after(part);
       J_new = wave_sum_uniform(part);
+      CILQR_SUB(4, J_new)
     }
     j_valid = true;
     __syncthreads();
@@ -867,7 +911,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
       }
       break;
     }
-    if (!(GENERAL ? riccati<true>(kp, N, rec, kK, lamb) : riccati_mfma<FSMEM>(N, rec, kK, fwd, cst, 2.0 / kp.dt, lamb))) {
+    if (!(GENERAL ? riccati<true>(kp, N, rec, kK, lamb) : riccati_mfma<FSMEM, DIAG>(N, rec, kK, fwd, cst, 2.0 / kp.dt, lamb, sub))) {
       if (GENERAL) { status = CILQR_EXIT_NUMERIC; break; }
       handover = true;
       break;
@@ -925,8 +969,9 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
   }
   if (DIAG && lane == 0 && a.diag) {
     const unsigned long long now_ = __builtin_readcyclecounter();
-    unsigned long long* o = a.diag + (size_t)b * 8;
+    unsigned long long* o = a.diag + (size_t)b * DIAG_SLOTS;
     o[0] = c_pro; o[1] = c_L; o[2] = c_R; o[3] = c_F; o[4] = now_ - tk; o[5] = n_L; o[6] = n_R; o[7] = now_ - tk0;
+    for (int q = 0; q < 8; ++q) o[8 + q] = sub[q];
   }
 #undef CILQR_STAMP
 }

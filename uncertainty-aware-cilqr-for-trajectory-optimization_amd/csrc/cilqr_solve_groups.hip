@@ -478,7 +478,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_fast(SolveArgs a, dou
     if (g == 0) ae.J_out[b] = J_new;
   }
   if (a.diag && g == 0) {  // {prologue, L, R, F, epilogue, #L, #R, total}: prologue/epilogue not separated here
-    unsigned long long* d = a.diag + (size_t)b * 8;
+    unsigned long long* d = a.diag + (size_t)b * DIAG_SLOTS;
     d[0] = 0; d[1] = tL; d[2] = tR; d[3] = tF; d[4] = 0; d[5] = nL; d[6] = nR; d[7] = __builtin_readcyclecounter() - t_begin;
   }
   if (g == 0) {
