@@ -29,14 +29,35 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (cannot be collected inside this process): FETCH_SIZE
-# doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950, plus WRITE_SIZE.  Keyed by (workload, batch).
-PMC_TRAFFIC_BYTES = {("c2", 1024): 2 * 12309.8e3 + 10008.8e3,   # profiles/r02_solver_summary.md (forward-pass records through L2 included)
-                     ("c3", 4096): 2 * 345934e3 + 114076e3,     # compact sampled form (materialised: ≈ 23 GB)
-                     ("c5", 8192): 2 * 1.70466e9 + 1.83323e9,   # the global workspace of the grouped family (r01: 8.42 GB)
-                     # profiles/r01_wide_rows_summary.md (KB per dispatch): the 1024^2 destination reads a 512^2 patch of the source
-                     ("warp", 1024): 2 * 598.438e3 + 4096e3,
-                     ("occ", 8192): 2 * 131103e3 + 65536e3}
+# Recorded (NOT live) figures: HBM bytes per launch of the dominant kernel and its issue counters come from rocprofv3 --pmc
+# passes, which cannot be collected inside this process.  They are read from the newest profiles/rNN_pmc.json — written by
+# tools/prof_summary.py from the committed rocprofv3 summaries — and every block that carries one is tagged with the file and
+# the commit the profiled build was made from ("recorded_from", "recorded_head").  FETCH_SIZE is doubled as
+# MI355X_MICROARCH.md §HBM prescribes for gfx950.
+
+
+def _load_recorded():
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")))
+    if not files:
+        return {"workloads": {}, "recorded_head": None}, None
+    return json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
+
+
+RECORDED, RECORDED_FROM = _load_recorded()
+# the batch size each record was profiled at: a record describes that launch only
+RECORDED_BATCH = {"c2": 1024, "c3": 4096, "c5": 8192, "warp": 1024, "warp16": 1024, "occ": 8192}
+
+
+def recorded_traffic(workload, size):
+    """(HBM bytes per launch, tag) of the dominant kernel from the recorded PMC passes, or (None, None)."""
+    rec = RECORDED["workloads"].get(workload)
+    if rec is None or RECORDED_BATCH.get(workload) != size or "hbm_bytes_per_launch" not in rec:
+        return None, None
+    return rec["hbm_bytes_per_launch"], {"recorded_from": RECORDED_FROM, "recorded_head": RECORDED.get("recorded_head"),
+                                          "summary": rec.get("source"), "formula": "2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes"}
+
+
 FP64_VALU_PEAK_TF = 78.6   # vector fp64 = half the 157.3 TF fp32 vector peak of MI355X_MICROARCH.md
 
 
@@ -145,8 +166,8 @@ def bench_warp(args, rank, local_rank, world, dist, dev):
                "config": {"workload": ("BASELINE config 4: " if S == 1024 else "size sweep: ") +
                                       "%dx%d occupancy costmap warp, %d frame(s) per step and launch, maps resident in HBM" % (S, S, K)},
                "roofline": {"bound": "hbm", "kernel": "warp_kernel" if K == 1 else "warp_batch_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC_BYTES.get(("warp", S)) if K == 1 else None,
-                            "traffic_source": "profiles/r01_wide_rows_summary.md (FETCH_SIZE x2 + WRITE_SIZE)" if S == 1024 and K == 1 else None,
+                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": recorded_traffic("warp" if K == 1 else "warp%d" % K, S)[0],
+                            "traffic_source": recorded_traffic("warp" if K == 1 else "warp%d" % K, S)[1],
                             "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch}}
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a rank-0, N=1 measurement
             from oracle import oracle as O
@@ -314,8 +335,7 @@ def bench_occ(args, rank, local_rank, world, dist, dev):
                     n * args.steps * world / elapsed, args, world, elapsed, "i8 / f32",
                     "SURVEY 8f-4: fromOccupancyGrid + toOccupancyGrid(-1, 100) round trip, %d cells, buffers resident in HBM" % n,
                     {"bound": "hbm", "kernel": "layer_to_occ_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC_BYTES.get(("occ", S)),
-                     "traffic_source": "profiles/r01_wide_rows_summary.md (FETCH_SIZE x2 + WRITE_SIZE)" if S == 8192 else None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": recorded_traffic("occ", S)[0], "traffic_source": recorded_traffic("occ", S)[1],
                      "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch})
         to_layer_ms = float(np.mean([a.elapsed_time(b) for a, b in first]))
         out["occ_to_layer_kernel"] = {"kernel_ms": to_layer_ms, "achieved": bytes_launch / (to_layer_ms * 1e-3) / 1e9, "unit": "GB/s",
@@ -688,6 +708,9 @@ def main():
         # first rejected iteration): linearisations·N·(6S + 100M) + passes·N·800.
         flops_ref = mean_iters * N * (6 * 200 + 100 * M + 800)
         flops_solve = mean_lin * N * (6 * 200 + 100 * M) + mean_passes * N * 800
+        # which kernel family the library picks for this shape: asked, not restated (cilqr_solve_family)
+        lanes = 64 if sampled else solver.solve_family(B, N, M)
+        traffic, traffic_tag = (None, None) if (args.workload == "c3" and args.materialised) else recorded_traffic(args.workload, B)
         out = {
             "metric": "CILQR solves/sec (N=%d, batch B)" % N, "value": value, "unit": "solves/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -695,11 +718,9 @@ def main():
             "config": {"workload": wl + ", inputs resident in HBM, + min-cost selection",
                        "batch_per_gpu": B, "horizon": N, "obstacles": M, "mean_reference_iterations": mean_iters,
                        "parallelism": "scene-sharded x%d, one ncclAllGather of 24 B per rank behind cilqr_argmin_global_device" % world},
-            "roofline": {"bound": "hbm", "kernel": "cilqr_solve_kernel" if (B <= 2048 or M > 32 or (N <= 64 and B <= 8192)) else "cilqr_solve_groups_fast", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None if (args.workload == "c3" and args.materialised) else PMC_TRAFFIC_BYTES.get((args.workload, B)),
-                         "traffic_source": "profiles/r02_solver_summary.md (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
-                         if (args.workload, B) in PMC_TRAFFIC_BYTES and not (args.workload == "c3" and args.materialised) else None,
+            "roofline": {"bound": "hbm", "kernel": "cilqr_solve_kernel" if lanes == 64 else "cilqr_solve_groups_fast<%d>" % lanes,
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_tag,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch,
                          "note": "issue-bound path of one wavefront per SIMD: HBM fraction is tiny by design (LDS-resident solve); see fp64_valu"},
             "fp64_valu": {"achieved_tflops_est": flops_solve * B / (kern_ms * 1e-3) / 1e12, "peak_tflops": FP64_VALU_PEAK_TF,
@@ -713,7 +734,7 @@ def main():
                                                          "note": "counts the rejected iterations the reference loop repeats and the kernel skips"}},
             "min_cost": {"J": best[0], "global_index": best[1]},
         }
-        wave_family = out["roofline"]["kernel"] == "cilqr_solve_kernel"
+        wave_family = lanes == 64
         if wave_family and B > 1024 and world == 1:
             # Batches beyond one solve per SIMD are dispatched longest-first by the pass counts of the PREVIOUS call (DESIGN.md
             # §4.1d).  The timed steps repeat one batch, the best case for that hint; beside it the same launch on a handle
@@ -734,11 +755,17 @@ def main():
             out["schedule_hint"] = {"active": True, "kernel_ms_without_hint": cold_ms, "solves_per_s_without_hint": B / (cold_ms * 1e-3),
                                     "note": "value and roofline.kernel_ms are steady state on a repeated batch: the solves are dispatched "
                                             "longest-first by the previous call's pass counts; without_hint = same launch, dispatch in index order"}
-        if args.workload == "c2" and B == 1024:  # PMC pass of the same command (profiles/r02_solver_summary.md, per launch)
-            out["issue"] = {"instruction_issue_cycles": 64.4e6, "wavefront_cycles": 98.4e6, "frac": 64.4 / 98.4,
-                            "valu_insts": 46.2e6, "salu_insts": 5.6e6, "lds_insts": 3.5e6,
-                            "note": "one wavefront per SIMD on a serial chain: the path is bound by the issue rate of a lone wavefront "
-                                    "(one instruction per 5.2 ticks, a matrix instruction 16.2), SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES"}
+        cnt = RECORDED["workloads"].get(args.workload, {}).get("counters", {})
+        if traffic_tag and "SQ_WAVE_CYCLES" in cnt:  # SQ counter pass of the same command, per launch: recorded, not live
+            out["issue"] = {"recorded_from": RECORDED_FROM, "recorded_head": RECORDED.get("recorded_head"),
+                            "instruction_issue_cycles": cnt.get("SQ_ACTIVE_INST_ANY"), "wavefront_cycles": cnt["SQ_WAVE_CYCLES"],
+                            "frac": cnt.get("SQ_ACTIVE_INST_ANY", 0.0) / cnt["SQ_WAVE_CYCLES"],
+                            "wait_inst_any_frac": cnt.get("SQ_WAIT_INST_ANY", 0.0) / cnt["SQ_WAVE_CYCLES"],
+                            "valu_insts": cnt.get("SQ_INSTS_VALU"), "mfma_f64_insts": cnt.get("SQ_INSTS_VALU_MFMA_F64"),
+                            "salu_insts": cnt.get("SQ_INSTS_SALU"), "lds_insts": cnt.get("SQ_INSTS_LDS"),
+                            "l2_hit_frac": (cnt["TCC_HIT_sum"] / cnt["TCC_REQ_sum"]) if cnt.get("TCC_REQ_sum") else None,
+                            "note": "SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES: share of resident-wavefront cycles in which an instruction "
+                                    "issued (a lone wavefront issues one per 5.2 ticks, a matrix instruction 16.2)"}
         # SURVEY §8(d) also asks for the host-buffer entry point (H2D + kernel + D2H); reported, never `value`
         reps = (5 if M <= 16 else 1) if world == 1 else 0
         if reps:

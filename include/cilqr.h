@@ -358,6 +358,12 @@ int cilqr_set_diag_buffer(cilqr_handle* h, uint64_t* dev_buf);
  * with it.  NULL switches it off. */
 int cilqr_set_pass_count_buffer(cilqr_handle* h, int32_t* dev_buf);
 
+/* Which kernel family a solve of this shape takes on this handle: the number of lanes per solve — 64 = one
+ * wavefront per solve, LDS-resident (cilqr_solve.hip); 32 … 1 = the grouped family (cilqr_solve_groups.hip), 64/G solves per
+ * wavefront.  The same rule cilqr_solve_batch(_device) applies (CILQR_FORCE_G in the environment at create overrides it);
+ * measurement tools label their figures with it instead of restating the rule.  Negative: error code. */
+int cilqr_solve_family(const cilqr_handle* h, int B, int N, int M);
+
 /* Test hook: runs the kernels' own regularised Q_uu inverse (I/iLQR.cpp:155-175) on n column-major 2×2 matrices (host
  * buffers).  general = 0: the positive-semi-definite form of the production kernel; 1: the eigenvalue-clamping form of the
  * GENERAL kernel (NaN rows where it reports a non-finite matrix).  Lets the rarely taken branch be checked against the

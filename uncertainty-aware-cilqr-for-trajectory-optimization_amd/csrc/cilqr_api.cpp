@@ -67,6 +67,27 @@ hipError_t dmalloc(T** p, size_t n) {
 
 }  // namespace
 
+// Kernel family by batch shape (measured with tools/family_shapes.py, profiles/r03_family_shapes.txt): lanes per
+// solve, 64 = the one-wavefront-per-solve family (cilqr_solve.hip), less = the grouped family (cilqr_solve_groups.hip).  One
+// wavefront per solve, LDS-resident, up to two solves per SIMD (2048 on an MI355X) whatever the horizon, and up to eight when
+// the horizon fits one round of lanes (N ≤ 64): since the backward pass runs on the matrix cores, the forward pass takes its
+// operands through the scalar path and the workgroups are dispatched longest-first (schedule hint below), further wavefronts
+// on a SIMD cost that family less than the grouped family pays in global-memory traffic (config-2 scenes: B = 4096 0.53 ms
+// against 1.10 ms grouped, B = 8192 0.96-0.99 against 1.38-1.42; M = 0 and M = 8 at B = 8192 5-7 % the other way; N = 80 at
+// B = 4096 2.25 against 1.73).  Beyond that G lanes per solve, G the power of two nearest below 64·SIMDs/B (at most 32).
+static int pick_group_lanes(const cilqr_handle* h, int B, int N, int M) {
+  const int f = h->force_g;
+  if (f == 1 || f == 2 || f == 4 || f == 8 || f == 16 || f == 32 || f == 64) return f;
+  int G = 64;
+  if (B > 2 * h->simds && M <= 32 && !(N <= 64 && B <= 8 * h->simds)) {
+    // (with hundreds of obstacle entries per step the solve is a stream over its obstacle table: the wavefront-per-solve
+    // family reads it as whole 400-640 B rows per instruction and measures ≈2x faster there — BASELINE config 3)
+    G = 32;
+    while (G > 1 && (long)G * B > 64L * h->simds) G >>= 1;
+  }
+  return G;
+}
+
 // The one-wavefront-per-solve family with a schedule hint.  A batch of more solves than SIMDs is dispatched in workgroup order,
 // and its launch ends when the last workgroup does: a 20-pass solve that starts among the last costs its full length on top of
 // everything else (config-2 scenes at B = 4096: 0.91 ms as given, 0.53 ms with the longest solves first; config 3: 3.8 → 2.4 ms,
@@ -361,6 +382,11 @@ int cilqr_wait(cilqr_handle* h) {
   return CILQR_OK;
 }
 
+int cilqr_solve_family(const cilqr_handle* h, int B, int N, int M) {
+  if (!h || B < 0 || N < 1 || M < 0) return fail(CILQR_ERR_ARG, "cilqr_solve_family: bad argument");
+  return pick_group_lanes(h, B, N, M);
+}
+
 int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M, const double* x0, double* U,
                              const double* poly, const double* xplan_fl, const double* obs_pose, const double* obs_dim,
                              const double* obs_weight, double* X_out, double* J_out, int32_t* iters_out,
@@ -385,22 +411,7 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
   a.B = B; a.N = N; a.M = M; a.flags = flags;
   a.kp = h->kp;
   HIP_TRY(hipSetDevice(h->device));
-  // Kernel family by batch size (measured with tools/family_shapes.py, profiles/r02_family_shapes.txt).  One
-  // wavefront per solve, LDS-resident, up to two solves per SIMD (2048 on an MI355X) whatever the horizon, and up to eight when
-  // the horizon fits one round of lanes (N ≤ 64): since the backward pass runs on the matrix cores, the forward pass takes its
-  // operands through the scalar path and the workgroups are dispatched longest-first (schedule hint above), further wavefronts
-  // on a SIMD cost that family less than the grouped family pays in global-memory traffic (config-2 scenes: B = 4096 0.53 ms
-  // against 1.10 ms grouped, B = 8192 0.96-0.99 against 1.38-1.42; M = 0 and M = 8 at B = 8192 5-7 % the other way; N = 80 at
-  // B = 4096 2.25 against 1.73).  Beyond that G lanes per solve, G the power of two nearest below 64·SIMDs/B (at most 32).
-  int G = 64;
-  if (h->force_g == 1 || h->force_g == 2 || h->force_g == 4 || h->force_g == 8 || h->force_g == 16 || h->force_g == 32 || h->force_g == 64) {
-    G = h->force_g;
-  } else if (B > 2 * h->simds && M <= 32 && !(N <= 64 && B <= 8 * h->simds)) {
-    // (with hundreds of obstacle entries per step the solve is a stream over its obstacle table: the wavefront-per-solve
-    // family reads it as whole 400-640 B rows per instruction and measures ≈2x faster there — BASELINE config 3)
-    G = 32;
-    while (G > 1 && (long)G * B > 64L * h->simds) G >>= 1;
-  }
+  const int G = pick_group_lanes(h, B, N, M);
   if (G == 64 && cilqr::solve_lds_bytes(N, h->kp.n_samples) > cilqr::SOLVE_LDS_MAX)
     return fail(CILQR_ERR_UNSUPPORTED, "cilqr_solve_batch: horizon %d needs %zu bytes of LDS per solve (limit %zu)", N,
                 cilqr::solve_lds_bytes(N, h->kp.n_samples), cilqr::SOLVE_LDS_MAX);
