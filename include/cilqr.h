@@ -250,6 +250,11 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
  *              q2 = q2_uncertainty (I/Parameters.cpp:41-42); ∇c is taken with respect to (x, y) only — the heading's effect on the
  *              probe positions is ignored, as the reference ignores it for its ego circles (I/Obstacle.cpp:75-78);
  *   result     the mean over the probes.
+ *   omitted    (stated so that nobody reads more into vx, mx than is there) vx has no heading entry: d/dθ of the cost through the
+ *              turning footprint is dropped (vx[2] = vx[3] = 0); mx is the Gauss-Newton outer product only: the interpolant's own
+ *              curvature (the bilinear cross term ∂²o/∂x∂y) and every θ row and column are dropped.  The x, y entries of vx ARE
+ *              the exact derivative of the cost at fixed heading (checked by finite differences, tests/test_oracle.py and the
+ *              -m gpu twin on the kernel's own value).
  * cilqr_set_uncertainty_map_device: every pointer in *map is a device pointer that must stay valid (and is read) during later
  * solves — e.g. the uncertainty_layer cilqr_costmap_frame_device wrote on the same stream.  cilqr_set_uncertainty_map: host
  * pointers; one shared layer (layer_stride = 0, poses = NULL) copied into a buffer the handle owns.  Both return

@@ -413,6 +413,66 @@ def test_several_wavefronts_per_simd(cilqr, oracle, B, N, M):
     assert np.isfinite(got["U"]).all() and (got["iters"] >= 1).all()
 
 
+def _pair_vs_single(cilqr, monkeypatch, sc, N, M, B):
+    """The same batch on a handle that may use the two-wavefront kernel and on one created with CILQR_NO_PAIR_KERNEL."""
+    p = cilqr.default_params(N)
+    two = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=max(M, 1), device=0)
+    monkeypatch.setenv("CILQR_NO_PAIR_KERNEL", "1")
+    one = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=max(M, 1), device=0)
+    monkeypatch.delenv("CILQR_NO_PAIR_KERNEL")
+    try:
+        return _gpu_batch(two, sc), _gpu_batch(one, sc)
+    finally:
+        two.close()
+        one.close()
+
+
+@pytest.mark.parametrize("N,M,B", [(50, 4, 1024), (30, 2, 200), (2, 1, 9), (3, 0, 5), (17, 5, 64), (64, 4, 96), (72, 3, 40), (33, 9, 70)])
+def test_pair_kernel_equals_single_wavefront_kernel(cilqr, oracle, monkeypatch, N, M, B):
+    """Up to one solve per SIMD every solve runs as a workgroup of two wavefronts (cilqr_solve_pair_kernel: the linearisation of
+    the new trajectory runs on the second wavefront behind the forward pass, four lanes per step).  It must return the bits of
+    the one-wavefront kernel — U, X, J, iteration counts, exits — on config 2 in full and on ragged shapes: horizons that are no
+    multiple of the 16-step chunks, obstacle counts that are no multiple of the quad, none at all, N > 64; and both must agree
+    with the oracle."""
+    from cilqr_amd import scenes
+    p = cilqr.default_params(N)
+    sc = scenes.make_static(B, N, M, p, 7100 + N)
+    got, ref = _pair_vs_single(cilqr, monkeypatch, sc, N, M, B)
+    for k in ("iters", "status", "U", "X", "J"):
+        assert np.array_equal(got[k], ref[k]), "%s differs in %d solves" % (k, int(np.any(np.atleast_2d(got[k].T != ref[k].T), axis=0).sum()))
+    idx = np.arange(min(B, 128))
+    sub = {k: (v[idx] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in sc.items()}
+    _compare({k: v[idx] for k, v in got.items()}, _oracle_batch(oracle, N, sub), TIGHT, "two wavefronts per solve")
+
+
+def test_pair_kernel_weights_warm_starts_and_hand_over(cilqr, oracle, monkeypatch):
+    """The two-wavefront kernel with per-obstacle weights, warm-started (random) controls, moving obstacles, and solves that it
+    hands to the GENERAL kernel (a NaN start, a heading beyond the in-loop sincos range, a turn of more than 1/4 rad per step):
+    the bits of the one-wavefront kernel, and the oracle's results where it has finite ones."""
+    from cilqr_amd import scenes
+    N, M, B = 50, 6, 160
+    p = cilqr.default_params(N)
+    sc = scenes.make_static(B, N, M, p, 7177)
+    rng = np.random.default_rng(7177)
+    sc["obs_weight"] = rng.uniform(0.2, 2.0, (B, M))
+    sc["U"] = sc["U"] + rng.normal(0.0, 0.3, sc["U"].shape)
+    pose = sc["obs_pose"].reshape(B, M, N, 4).copy()
+    pose[:, 0, :, 2] = 3.0  # a moving obstacle: speed inflates its ellipse (I/Obstacle.cpp:42-43)
+    pose[:, 0, :, 0] += 0.3 * np.arange(N)
+    sc["obs_pose"] = pose.reshape(B, M, 4 * N)
+    sc["x0"][3, 1] = np.nan
+    sc["x0"][5, 3] = 2.0e6
+    sc["x0"][7, 2] = 25.0
+    sc["U"][7, 1::2] = 5.0  # full lock at 25 m/s: more than 1/4 rad per step
+    got, ref = _pair_vs_single(cilqr, monkeypatch, sc, N, M, B)
+    for k in ("iters", "status", "U", "X", "J"):
+        assert np.array_equal(got[k], ref[k], equal_nan=True), k
+    keep = np.ones(B, bool)
+    keep[[3]] = False
+    sub = {k: (v[keep] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in sc.items()}
+    _compare({k: v[keep] for k, v in got.items()}, _oracle_batch(oracle, N, sub), TIGHT, "two wavefronts, weights and warm starts")
+
+
 def test_schedule_hint_changes_nothing_but_the_order(cilqr):
     """A batch beyond one solve per SIMD is dispatched longest-first by the pass counts of the previous call (same batch size,
     same stream).  Every call must return bit-identical results — the first (identity order), the second (hinted) and a third
@@ -1507,6 +1567,43 @@ def test_uncertainty_cost_kernel_vs_oracle(cilqr, oracle):
         assert np.allclose(cost, wc, rtol=1e-11, atol=1e-14)
         assert np.allclose(vx, wv[:, :2], rtol=1e-11, atol=1e-12)
         assert np.allclose(mx, np.stack([wm[:, 0, 0], wm[:, 0, 1], wm[:, 1, 1]], 1), rtol=1e-11, atol=1e-12)
+
+
+def test_uncertainty_cost_kernel_gradient_by_finite_differences(cilqr, oracle):
+    """Self-consistency of the map cost on the device, independent of the formula it shares with its plain-C statement (ADVICE
+    r02): vx must be the derivative of the kernel's OWN cost value with respect to (x, y) at fixed heading (central differences
+    of cilqr_debug_uncertainty_cost), and with one probe mx must be the Gauss-Newton form vx vx' / x of that value.  A probe
+    within the step of a cell-centre line sees the interpolant's kink: those few states are excluded, as in the oracle's test."""
+    geom, layer = _unc_layer(oracle, 0)
+    g = cilqr.map_geom(*geom)
+    p = _unc_params(cilqr, 50)
+    rng = np.random.default_rng(23)
+    pose = (2.0, -1.0, 0.3)
+    q = np.stack([rng.uniform(2, 28, 256), rng.uniform(-8, 8, 256)], 1)
+    c, sn = np.cos(pose[2]), np.sin(pose[2])
+    st = np.stack([pose[0] + c * q[:, 0] - sn * q[:, 1], pose[1] + sn * q[:, 0] + c * q[:, 1], np.full(256, 3.0), rng.uniform(-0.5, 0.5, 256)], 1)
+    s = cilqr.Solver(p, max_batch=1, max_horizon=8, max_obstacles=0, device=0)
+    try:
+        s.set_uncertainty_map(layer, g, pose, (3, 3))
+        cost, vx, mx = s.debug_uncertainty_cost(st)
+        h = 1e-6
+        for k in range(2):
+            d = np.zeros(4)
+            d[k] = h
+            cp, _, _ = s.debug_uncertainty_cost(st + d)
+            cm, _, _ = s.debug_uncertainty_cost(st - d)
+            fd = (cp - cm) / (2 * h)
+            smooth = np.abs(fd - vx[:, k]) < 1e-4 * (1 + np.abs(vx[:, k]))
+            assert smooth.mean() > 0.9, (k, smooth.mean())
+        assert (np.abs(vx).max(axis=1) > 1e-3).sum() > 20  # the scene does exercise the gradient
+        s.set_uncertainty_map(layer, g, pose, (1, 1))
+        c1, v1, m1 = s.debug_uncertainty_cost(st)
+    finally:
+        s.close()
+    on = c1 > 0
+    assert on.sum() > 100
+    gn = np.stack([v1[:, 0] * v1[:, 0], v1[:, 0] * v1[:, 1], v1[:, 1] * v1[:, 1]], 1)[on] / c1[on, None]
+    assert np.allclose(m1[on], gn, rtol=1e-11, atol=1e-300)
 
 
 @pytest.mark.parametrize("G", [0, 8])

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Kernel family by shape: wall time of cilqr_solve_batch_device for static scenes of several (N, M, B), default family choice
-against the one-wavefront-per-solve family forced (CILQR_FORCE_G=64).  Diagnostic tool."""
+"""Kernel family by shape: wall time of cilqr_solve_batch_device for static scenes of several (N, M, B) in BOTH families — one
+wavefront per solve (CILQR_FORCE_G=64) and G lanes per solve (CILQR_FORCE_G = the automatic G for that batch) — beside what the
+library's own rule picks (cilqr_solve_family) and what that pick loses against the faster family.  Each figure is the best of
+four launches of one batch, i.e. with the schedule hint active from the second launch on.  Diagnostic tool; its table is
+profiles/rNN_family_shapes.txt and the rule in cilqr_api.cpp (pick_group_lanes) is drawn from it."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "uncertainty-aware-cilqr-for-trajectory-optimization_amd")]
@@ -8,11 +11,18 @@ import numpy as np, torch
 import cilqr_amd
 from cilqr_amd import scenes
 
+_scene = {}
+
+
 def run(N, M, B, force):
     if force: os.environ["CILQR_FORCE_G"] = str(force)
     else: os.environ.pop("CILQR_FORCE_G", None)
     p = cilqr_amd.default_params(N)
-    sc = scenes.make_static(B, N, M, p, scenes.SEED0 + 2)
+    key = (N, M, B)
+    if key not in _scene:
+        _scene.clear()
+        _scene[key] = scenes.make_static(B, N, M, p, scenes.SEED0 + 2)
+    sc = _scene[key]
     s = cilqr_amd.Solver(p, max_batch=B, max_horizon=N, max_obstacles=max(M, 1))
     dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     x0, U, poly, xpl = dv(sc["x0"]), dv(sc["U"]), dv(sc["poly"]), dv(sc["xplan_fl"])
@@ -31,13 +41,25 @@ def run(N, M, B, force):
         e1.record()
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1))
-    return best, float(it.float().mean())
+    fam = s.solve_family(B, N, M)
+    s.close()
+    return best, float(it.float().mean()), fam
 
-shapes = [(30, 2), (50, 0), (50, 4), (50, 8), (50, 12), (80, 4), (80, 8), (80, 16), (100, 4), (120, 4), (120, 16), (160, 4)]
+shapes = [(30, 2), (50, 0), (50, 4), (50, 8), (50, 12), (64, 4), (72, 4), (80, 4), (80, 8), (80, 16), (100, 4), (100, 16), (120, 4), (120, 16), (160, 4), (160, 16)]
 if os.environ.get("SHAPES"):
     shapes = [tuple(int(v) for v in q.split("x")) for q in os.environ["SHAPES"].split(",")]
+worst = 0.0
 for N, M in shapes:
     for B in (2048, 4096, 8192, 16384):
-        a, ia = run(N, M, B, 0)
-        b, ib = run(N, M, B, 64)
-        print("N=%3d M=%2d B=%5d  default %.3f ms | wavefront family %.3f ms  (mean iterations %.1f / %.1f)" % (N, M, B, a, b, ia, ib), flush=True)
+        G = 32
+        while G > 1 and G * B > 64 * 1024:
+            G >>= 1
+        _, _, fam = run(N, M, B, 0)
+        w, iw, _ = run(N, M, B, 64)
+        g, ig, _ = run(N, M, B, G)
+        pick = w if fam == 64 else g
+        loss = pick / min(w, g) - 1.0
+        worst = max(worst, loss)
+        print("N=%3d M=%2d B=%5d  wavefront family %7.3f ms | grouped (G=%2d) %7.3f ms | rule picks %s: loses %4.1f %%  (mean iterations %.1f / %.1f)"
+              % (N, M, B, w, G, g, "wavefront" if fam == 64 else "grouped G=%d" % fam, 100 * loss, iw, ig), flush=True)
+print("largest loss of the rule against the faster family: %.1f %%" % (100 * worst))

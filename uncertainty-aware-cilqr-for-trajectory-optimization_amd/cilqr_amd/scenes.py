@@ -96,7 +96,7 @@ def make_static(B, N, M, params, seed, local_plan=None):
     pose, dim = _obstacles(rng, curve, B, M, N, params.timestep, 0.0)
     return dict(N=N, M=M, x0=x0, U=_default_U(B, N), poly=poly, xplan_fl=xplan,
                 obs_pose=pose.reshape(B, M, 4 * N) if M else None, obs_dim=dim.reshape(B, M, 2 * N) if M else None,
-                obs_weight=None)
+                obs_weight=None, curve=curve)
 
 
 def make_c2(B=1024, params=None, local_plan=None):
@@ -127,7 +127,83 @@ def make_c3(B=4096, params=None, local_plan=None, n_dyn=8, n_samples=32):
                 obs_pose=poses.reshape(B, M, 4 * N), obs_dim=dims.reshape(B, M, 2 * N), obs_weight=w,
                 # the same obstacles in compact form (cilqr_solve_batch_sampled): nominal trajectories + per-sample offsets
                 nom_pose=pose.reshape(B, n_dyn, 4 * N), nom_dim=dim.reshape(B, n_dyn, 2 * N), offsets=off,
-                sample_weight=1.0 / n_samples)
+                sample_weight=1.0 / n_samples, curve=curve)
+
+
+POSE_SIGMA = np.array([0.16, 0.16, 0.017])  # ilqr/launch/Experiment.launch:9-11 (sigma_x, sigma_y, sigma_theta)
+
+
+class TickSequence:
+    """A closed-loop sequence of planner ticks over a batch of scenes — what a planner really hands the solver call after call,
+    as opposed to one batch solved again and again.  Tick 0 is the benchmark batch itself (`kind` = "c3": make_c3; "static":
+    make_static with the given seed).  `advance(X, U)` takes the results of the current tick and forms the next one the way the
+    reference node does between two `run_step` calls:
+      * ego <- X[:, 1], the state the accepted plan reaches after one timestep (the node re-reads odometry; this is its noise-free
+        stand-in);
+      * U: the result, kept UN-SHIFTED as the warm start (iLQR::control_seq persists across run_step calls, I/iLQR.cpp:253);
+      * the local plan is re-fitted around the new ego (LocalPlanner pre-step on the same global path, I/LocalPlanner.cpp:25-117);
+      * obstacles move on by one timestep along their headings (static ones stay);
+      * "c3": every tick draws fresh pose noise for the samples with the launch file's sigmas (the node perturbs the
+        obstacle poses anew in every callback, I/ilqr_uncertainty_node.cpp:82-110).
+    Host-side numpy; the arrays of `inputs()` have the layouts of include/cilqr.h (compact sampled form for "c3")."""
+
+    def __init__(self, kind, B, params, N=50, M=4, seed=None, local_plan=None, n_dyn=8, n_samples=32):
+        self.kind, self.B, self.N, self.params = kind, B, N, params
+        self.local_plan = local_plan or _default_local_plan()
+        if kind == "c3":
+            sc = make_c3(B, params, self.local_plan, n_dyn, n_samples)
+            pose, dim = sc["nom_pose"].reshape(B, n_dyn, N, 4), sc["nom_dim"].reshape(B, n_dyn, N, 2)
+            self.offsets, self.sample_weight, self.n_obs = sc["offsets"], sc["sample_weight"], n_dyn
+            self.rng = np.random.Generator(np.random.PCG64(SEED0 + 3 + 7919))  # the noise of the later ticks
+        else:
+            sc = make_static(B, N, M, params, SEED0 + 2 if seed is None else seed, self.local_plan)
+            pose, dim = sc["obs_pose"].reshape(B, M, N, 4), sc["obs_dim"].reshape(B, M, N, 2)
+            self.offsets, self.sample_weight, self.n_obs = None, None, M
+            self.rng = None
+        self.curve = sc["curve"]
+        self.x0, self.U, self.poly, self.xplan = sc["x0"].copy(), sc["U"].copy(), sc["poly"].copy(), sc["xplan_fl"].copy()
+        self.p0 = pose[:, :, 0, :2].copy()                               # obstacle positions at the current tick
+        self.speed, self.head = pose[:, :, 0, 2].copy(), pose[:, :, 0, 3].copy()
+        self.dim = dim
+        self.tick = 0
+
+    def _poses(self):
+        t = np.arange(self.N) * self.params.timestep
+        pose = np.zeros((self.B, self.n_obs, self.N, 4))
+        pose[..., 0] = self.p0[..., 0, None] + (self.speed * np.cos(self.head))[..., None] * t
+        pose[..., 1] = self.p0[..., 1, None] + (self.speed * np.sin(self.head))[..., None] * t
+        pose[..., 2] = self.speed[..., None]
+        pose[..., 3] = self.head[..., None]
+        return pose
+
+    def inputs(self):
+        B, N, n = self.B, self.N, self.n_obs
+        d = dict(N=N, x0=self.x0, U=self.U, poly=self.poly, xplan_fl=self.xplan, tick=self.tick)
+        pose = self._poses()
+        if self.kind == "c3":
+            d.update(M=n * self.offsets.shape[2], nom_pose=pose.reshape(B, n, 4 * N), nom_dim=self.dim.reshape(B, n, 2 * N),
+                     offsets=self.offsets, sample_weight=self.sample_weight)
+        else:
+            d.update(M=n, obs_pose=pose.reshape(B, n, 4 * N), obs_dim=self.dim.reshape(B, n, 2 * N), obs_weight=None)
+        return d
+
+    def advance(self, X, U):
+        """X (B, 4(N+1)), U (B, 2N): the solver's results for the current tick."""
+        A, om, ph = self.curve
+        dt = self.params.timestep
+        self.x0 = np.ascontiguousarray(np.asarray(X).reshape(self.B, self.N + 1, 4)[:, 1, :])
+        self.U = np.ascontiguousarray(np.asarray(U).reshape(self.B, 2 * self.N))
+        self.p0[..., 0] += self.speed * np.cos(self.head) * dt
+        self.p0[..., 1] += self.speed * np.sin(self.head) * dt
+        xs = np.arange(200.0)
+        for b in range(self.B):
+            path = np.stack([xs, A[b] * np.sin(om[b] * xs + ph[b])], 1)
+            c, ref = self.local_plan(self.params, path, self.x0[b])
+            self.poly[b] = c
+            self.xplan[b] = (ref[0, 0], ref[-1, 0])
+        if self.kind == "c3":
+            self.offsets = self.rng.normal(0.0, 1.0, self.offsets.shape) * POSE_SIGMA
+        self.tick += 1
 
 
 def make_c4(seed=SEED0 + 4, size=1024):

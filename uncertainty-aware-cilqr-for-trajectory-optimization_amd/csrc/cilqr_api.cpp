@@ -99,6 +99,9 @@ static int launch_wave_scheduled(cilqr_handle* h, cilqr::SolveArgs& a, void* str
   const bool hinted = !h->hint_off && a.B > h->simds;
   a.order = hinted && h->hint_B == a.B && h->hint_stream == stream ? h->d_order : nullptr;
   a.hint_passes = hinted ? h->d_hint_passes : nullptr;
+  // up to one solve per SIMD every solve can have a second wavefront on another SIMD of its CU (cilqr_solve_pair_kernel); with
+  // more solves than SIMDs the second wavefronts would take the register space of solves waiting to start
+  a.pair = !h->pair_off && a.B <= h->simds ? 1 : 0;
   HIP_TRY(cilqr::launch_solve_wave(a, (hipStream_t)stream));
   if (hinted) {
     HIP_TRY(cilqr::launch_schedule_order(h->d_hint_passes, a.B, h->d_order, (hipStream_t)stream));
@@ -208,6 +211,7 @@ int cilqr_create(const cilqr_params* p, int max_batch, int max_horizon, int max_
   if (err == hipSuccess) err = dmalloc(&h->d_order, B);
   h->hint_B = 0; h->hint_stream = nullptr;
   h->hint_off = getenv("CILQR_NO_SCHEDULE_HINT") != nullptr;
+  h->pair_off = getenv("CILQR_NO_PAIR_KERNEL") != nullptr;
   if (err == hipSuccess) err = dmalloc(&h->d_pair, (size_t)2);
   if (err == hipSuccess) err = dmalloc(&h->d_triple, (size_t)3);
   if (err == hipSuccess) err = dmalloc(&h->d_gather, (size_t)3);
@@ -403,7 +407,7 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
   a.samp_off = nullptr; a.n_samples = 0; a.samp_w = 0.0;
   a.obs_tab = h->d_obs_tab;
   a.fwd = h->d_ws;  // (the grouped family's workspace: 42·N + 12 doubles per solve ≥ the 16·(N + 1) needed here; never both at once)
-  a.order = nullptr; a.hint_passes = nullptr;
+  a.order = nullptr; a.hint_passes = nullptr; a.pair = 0;
   a.redo = h->d_redo;
   a.diag = h->diag;
   a.passes = h->passes;
@@ -460,6 +464,7 @@ int cilqr_solve_batch_sampled_device(cilqr_handle* h, void* stream, int B, int N
   a.samp_off = sample_offset; a.n_samples = n_samples; a.samp_w = sample_weight;
   a.obs_tab = h->d_obs_tab;  // n_obs·N·8 doubles per solve ≤ the n_obs·n_samples·N·6 reserved for the materialised form
   a.fwd = h->d_ws;
+  a.pair = 0;
   a.redo = h->d_redo;
   a.diag = h->diag;
   a.passes = h->passes;

@@ -305,14 +305,20 @@ __device__ __forceinline__ void sample_xy(const SampleGrid& g, const double* pc,
 // so that is an index window around (px - xf)/dxs.  The window is widened by two samples and a 1e-4 relative margin (≫ any
 // rounding in its own computation), clamped to [0, S-1] and scanned in ascending order with strict <, which yields exactly
 // the reference's argmin, ties included.  `at(s, x, y)` supplies sample s.
+// The squared distance of sample s from (px, py), as every search below forms it.
 template <typename SampleAt>
-__device__ __forceinline__ int closest_sample(int S, const SampleGrid& g, double px, double py, SampleAt at) {
-  auto dist = [&](int s) {
-    double sx, sy;
-    at(s, sx, sy);
-    return (sx - px) * (sx - px) + (sy - py) * (sy - py);
-  };
-  int lo = 0, hi = S - 1;
+__device__ __forceinline__ double sample_dist(SampleAt at, int s, double px, double py) {
+  double sx, sy;
+  at(s, sx, sy);
+  return (sx - px) * (sx - px) + (sy - py) * (sy - py);
+}
+
+// The index window [lo, hi] that contains the argmin (see closest_sample): one statement of it for every search.
+template <typename SampleAt>
+__device__ __forceinline__ void closest_window(int S, const SampleGrid& g, double px, double py, SampleAt at, int& lo, int& hi) {
+  auto dist = [&](int s) { return sample_dist(at, s, px, py); };
+  lo = 0;
+  hi = S - 1;
   if (g.windowed) {
     const double fc = (px - g.xf) * g.inv_dxs;
     const double fcc = fmin(fmax(fc, 0.0), (double)(S - 1));  // NaN → 0
@@ -343,6 +349,13 @@ __device__ __forceinline__ int closest_sample(int S, const SampleGrid& g, double
       }
     }
   }
+}
+
+template <typename SampleAt>
+__device__ __forceinline__ int closest_sample(int S, const SampleGrid& g, double px, double py, SampleAt at) {
+  auto dist = [&](int s) { return sample_dist(at, s, px, py); };
+  int lo, hi;
+  closest_window(S, g, px, py, at, lo, hi);
   double md = dist(lo);
   int best = lo;
   for (int s = lo + 1; s <= hi; s += 4) {
@@ -457,6 +470,98 @@ struct Rec {
   double lx0, lx1, lx2, l00, l01, l11, lu0, lu1, luu0, luu1, al, be, ga, de, p, q;
 };
 
+// ---- pieces of one step's linearisation, shared by lin_step (one lane per step) and the four-lanes-per-step mapping of the
+// two-wavefront kernel (cilqr_solve.hip, linearize_quads): the same statements, so that both mappings give the same bits.
+struct ObsConsts {  // what every obstacle entry of one step needs of the ego state and the parameters
+  double fxp, fyp, rxp, ryp;  // the two ego circle centres (I/Obstacle.cpp:65-69, 86-90)
+  double q2f, q2r;            // barrier exponents' factors
+  double svf, smf, svr, smr;  // gradient / Hessian factors; the reference's factor -2 of c-dot (I/Obstacle.cpp:75-78) is carried
+                              // here (exact: powers of two), not applied to the vector
+};
+__device__ __forceinline__ ObsConsts make_obs_consts(const KParams& kp, double px, double py, double ct, double st) {
+  ObsConsts k;
+  k.fxp = px + ct * kp.ego_front; k.fyp = py + st * kp.ego_front;
+  k.rxp = px - ct * kp.ego_rear; k.ryp = py - st * kp.ego_rear;
+  k.q2f = kp.q2_front; k.q2r = kp.q2_rear;
+  k.svf = -2 * (kp.q2_front * kp.q1_front); k.smf = 4 * (kp.q2_front * kp.q2_front * kp.q1_front);
+  k.svr = -2 * (kp.q2_rear * kp.q1_rear); k.smr = 4 * (kp.q2_rear * kp.q2_rear * kp.q1_rear);
+  return k;
+}
+struct ObsPrep {  // an entry up to its barrier arguments
+  double g0[2], g1[2], arg[2];
+};
+// both circles up to the barrier argument c = 1 - d'Pd (I/Obstacle.cpp:65-73, 86-94)
+__device__ __forceinline__ void obs_prep(const ObsConsts& k, const ObsEntry& e, ObsPrep& p) {
+#pragma unroll
+  for (int side = 0; side < 2; ++side) {
+    const double ex = (side == 0 ? k.fxp : k.rxp) - e.ox, ey = (side == 0 ? k.fyp : k.ryp) - e.oy;
+    const double d0 = e.co * ex + e.so * ey;
+    const double d1 = e.co * ey - e.so * ex;
+    p.g0[side] = d0 * e.ia2;
+    p.g1[side] = d1 * e.ib2;
+    const double c = 1 - (p.g0[side] * d0 + p.g1[side] * d1);
+    p.arg[side] = (side == 0 ? k.q2f : k.q2r) * c;
+  }
+}
+// false: both barrier exponents are at or below -64 — the entry contributes less than e^-64 times O(10) factors at this step
+__device__ __forceinline__ bool obs_needed(const ObsPrep& p) { return !(p.arg[0] <= -64.0) || !(p.arg[1] <= -64.0); }
+struct ObsTerms {  // one entry's gradient and Hessian terms (front + rear circle), before its weight
+  double gx, gy, gxx, gxy, gyy;
+};
+__device__ __forceinline__ ObsTerms obs_terms(const ObsConsts& k, const ObsEntry& e, const ObsPrep& p) {
+  double gx = 0.0, gy = 0.0, gxx = 0.0, gxy = 0.0, gyy = 0.0;
+#pragma unroll
+  for (int side = 0; side < 2; ++side) {
+    const double h0 = e.co * p.g0[side] - e.so * p.g1[side];  // c-dot = -2 (h0, h1)
+    const double h1 = e.so * p.g0[side] + e.co * p.g1[side];
+    const double ee = exp_fast(p.arg[side]);
+    const double sv = (side == 0 ? k.svf : k.svr) * ee;
+    const double sm = (side == 0 ? k.smf : k.smr) * ee;
+    gx += sv * h0;
+    gy += sv * h1;
+    gxx += (sm * h0) * h0;
+    gxy += (sm * h0) * h1;
+    gyy += (sm * h1) * h1;
+  }
+  return ObsTerms{gx, gy, gxx, gxy, gyy};
+}
+struct StepSums {  // l_x(0,1), l_xx(00, 01, 11) of one step while its obstacle terms are added
+  double lx0, lx1, h00, h01, h11;
+};
+__device__ __forceinline__ void obs_accumulate(StepSums& a, const ObsTerms& g, double w) {
+  a.lx0 += g.gx * w;
+  a.lx1 += g.gy * w;
+  a.h00 += g.gxx * w;
+  a.h01 += g.gxy * w;
+  a.h11 += g.gyy * w;
+}
+// Control cost (I/Constraints.cpp:110-131): the arguments of its four barrier exponentials, then l_u, l_uu from their values.
+__device__ __forceinline__ void ctrl_args(const KParams& kp, double u0, double u1, double v, double& a1, double& a2, double& a3, double& a4) {
+  a1 = kp.q2_acc * (u0 - kp.acc_max);
+  a2 = kp.q2_acc * (kp.acc_min - u0);
+  a3 = kp.q2_yawrate * (u1 - v * kp.yaw_hi);
+  a4 = kp.q2_yawrate * (v * kp.yaw_lo - u1);
+}
+__device__ __forceinline__ void ctrl_terms(const KParams& kp, double u0, double u1, double e1, double e2, double e3, double e4, Rec& r) {
+  const double sa = kp.q2_acc * kp.q1_acc, sy = kp.q2_yawrate * kp.q1_yawrate;
+  const double ma = kp.q2_acc * kp.q2_acc * kp.q1_acc, my = kp.q2_yawrate * kp.q2_yawrate * kp.q1_yawrate;
+  r.lu0 = (sa * e1 - sa * e2) + (2 * kp.w_acc) * u0;
+  r.lu1 = (sy * e3 - sy * e4) + (2 * kp.w_yawrate) * u1;
+  r.luu0 = ma * e1 + ma * e2 + 2 * kp.w_acc;
+  r.luu1 = my * e3 + my * e4 + 2 * kp.w_yawrate;
+}
+// The six non-trivial Jacobian entries at (v_{t+1}, theta_{t+1}, a_t) (I/iLQR.cpp:102-106, I/Model.cpp:100-155)
+__device__ __forceinline__ void ab_terms(const KParams& kp, double u0, double vn, double cn, double sn, Rec& r) {
+  const double dt = kp.dt;
+  const double adv = vn * dt + u0 * kp.half_dt2;
+  r.al = dt * cn;            // A(2,0)
+  r.be = dt * sn;            // A(2,1)
+  r.ga = (-1) * sn * adv;    // A(3,0)
+  r.de = cn * adv;           // A(3,1)
+  r.p = kp.half_dt2 * cn;    // B(0,0)
+  r.q = kp.half_dt2 * sn;    // B(0,1)
+}
+
 // Constraints::get_state_cost / get_control_cost for one step (I/Constraints.cpp:145-227, 86-137; obstacles
 // I/Obstacle.cpp:39-112) plus the six non-trivial Jacobian entries at (v_{t+1}, theta_{t+1}, a_t) (I/iLQR.cpp:102-106,
 // I/Model.cpp:100-155).  (px,py,v,ct,st): state t with cos/sin of its heading; (vn,cn,sn): speed and cos/sin heading of
@@ -467,73 +572,37 @@ struct Rec {
 // O(10) factors to any sum — it is skipped after the 22 instructions that establish this, before its two exponentials.  The
 // gradient and Hessian sums it would have been added to are O(1e-3 … 1e3): the omission is below 1e-26 absolute, i.e. far
 // below one ulp of anything it feeds (measured: max|ΔU| against the oracle unchanged).  NaN exponents never vote to skip.
+// LANE_EXACT (with CULL): a step at which the entry is negligible adds exactly nothing, whatever the other steps of the vote need
+// (its weight is taken as 0) — the record of a step then depends on that step alone, not on which steps share its wavefront, so
+// the two-wavefront kernel, whose votes span other sets of steps, produces the same bits (cilqr_solve.hip).
 // The uncertainty-map term (I/Constraints.cpp:188-201) is NOT added here: the kernels add it to the stored record in a loop of
 // its own (unc_cost_add — after the obstacle terms, i.e. in the reference's order of summation), which keeps its registers out of
 // the obstacle loop's allocation (inlined here it cost the table-streaming configuration a third of its speed).
 // PAIRED (with CULL): entries are taken two at a time with four entries' loads in flight — for obstacle tables streamed from
 // global memory, where it is worth 12 % (config 3 materialised: 7.6 → 6.6 ms); where the entries come from LDS the extra live
 // registers cost more than the overlap brings (config 2 +2.4 %, config 3 compact +2 %), so it is off there.
-template <bool CULL = false, bool PAIRED = false, typename ObsAt>
+template <bool CULL = false, bool PAIRED = false, bool LANE_EXACT = false, typename ObsAt>
 __device__ __forceinline__ double lin_step(const KParams& kp, double px, double py, double v, double ct, double st, double u0,
                                            double u1, double vn, double cn, double sn, double cx, double cy, int M, ObsAt obs,
                                            Rec& r) {
-  const double dt = kp.dt;
   // --- tracking cost (I/Constraints.cpp:163-174)
   const double dx = px - cx, dy = py - cy, dv = v - kp.desired_speed;
-  double lx0 = (2 * kp.w_pos) * dx;
-  double lx1 = (2 * kp.w_pos) * dy;
+  StepSums a;
+  a.lx0 = (2 * kp.w_pos) * dx;
+  a.lx1 = (2 * kp.w_pos) * dy;
   const double lx2 = (2 * kp.w_vel) * dv;
-  double h00 = kp.w_pos * 2, h01 = 0.0, h11 = kp.w_pos * 2;
+  a.h00 = kp.w_pos * 2; a.h01 = 0.0; a.h11 = kp.w_pos * 2;
   const double J = stage_cost(kp, dx, dy, dv, u0, u1);
 
   // --- obstacles (I/Constraints.cpp:177-187, I/Obstacle.cpp:39-112)
-  const double fxp = px + ct * kp.ego_front, fyp = py + st * kp.ego_front;
-  const double rxp = px - ct * kp.ego_rear, ryp = py - st * kp.ego_rear;
-  // One obstacle entry into the gradient / Hessian sums.  The reference's factor -2 of c-dot (I/Obstacle.cpp:75-78) is
-  // carried in the scalar factors (exact: powers of two), not applied to the vector.
-  const double svf = -2 * (kp.q2_front * kp.q1_front), smf = 4 * (kp.q2_front * kp.q2_front * kp.q1_front);
-  const double svr = -2 * (kp.q2_rear * kp.q1_rear), smr = 4 * (kp.q2_rear * kp.q2_rear * kp.q1_rear);
-  struct Prep {  // an entry up to its barrier arguments
-    double g0[2], g1[2], arg[2];
-  };
-  // both circles up to the barrier argument c = 1 - d'Pd (I/Obstacle.cpp:65-73, 86-94)
-  auto prep = [&](const ObsEntry& e, Prep& p) {
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-      const double ex = (side == 0 ? fxp : rxp) - e.ox, ey = (side == 0 ? fyp : ryp) - e.oy;
-      const double d0 = e.co * ex + e.so * ey;
-      const double d1 = e.co * ey - e.so * ex;
-      p.g0[side] = d0 * e.ia2;
-      p.g1[side] = d1 * e.ib2;
-      const double c = 1 - (p.g0[side] * d0 + p.g1[side] * d1);
-      p.arg[side] = (side == 0 ? kp.q2_front : kp.q2_rear) * c;
-    }
-  };
+  const ObsConsts oc = make_obs_consts(kp, px, py, ct, st);
+  using Prep = ObsPrep;
+  auto prep = [&](const ObsEntry& e, Prep& p) { obs_prep(oc, e, p); };
   // the wave-wide vote of CULL: false when the entry is negligible at every step of the wavefront
-  auto wanted = [&](const Prep& p) {
-    const bool needed = !(p.arg[0] <= -64.0) || !(p.arg[1] <= -64.0);
-    return __builtin_amdgcn_ballot_w64(needed) != 0;
-  };
+  auto wanted = [&](const Prep& p) { return __builtin_amdgcn_ballot_w64(obs_needed(p)) != 0; };
   auto finish = [&](const ObsEntry& e, const Prep& p, double w) {
-    double gx = 0.0, gy = 0.0, gxx = 0.0, gxy = 0.0, gyy = 0.0;
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-      const double h0 = e.co * p.g0[side] - e.so * p.g1[side];  // c-dot = -2 (h0, h1)
-      const double h1 = e.so * p.g0[side] + e.co * p.g1[side];
-      const double ee = exp_fast(p.arg[side]);
-      const double sv = (side == 0 ? svf : svr) * ee;
-      const double sm = (side == 0 ? smf : smr) * ee;
-      gx += sv * h0;
-      gy += sv * h1;
-      gxx += (sm * h0) * h0;
-      gxy += (sm * h0) * h1;
-      gyy += (sm * h1) * h1;
-    }
-    lx0 += gx * w;
-    lx1 += gy * w;
-    h00 += gxx * w;
-    h01 += gxy * w;
-    h11 += gyy * w;
+    if (CULL && LANE_EXACT) w = obs_needed(p) ? w : 0.0;
+    obs_accumulate(a, obs_terms(oc, e, p), w);
   };
   if (CULL && PAIRED) {
     // Entries in PAIRS: the geometry of both first — two independent dependency chains that interleave (a lone wavefront issues a
@@ -597,27 +666,18 @@ __device__ __forceinline__ double lin_step(const KParams& kp, double px, double 
   }
 
   // --- control cost (I/Constraints.cpp:110-131)
-  const double e1 = exp_fast(kp.q2_acc * (u0 - kp.acc_max));
-  const double e2 = exp_fast(kp.q2_acc * (kp.acc_min - u0));
-  const double e3 = exp_fast(kp.q2_yawrate * (u1 - v * kp.yaw_hi));
-  const double e4 = exp_fast(kp.q2_yawrate * (v * kp.yaw_lo - u1));
-  const double sa = kp.q2_acc * kp.q1_acc, sy = kp.q2_yawrate * kp.q1_yawrate;
-  const double ma = kp.q2_acc * kp.q2_acc * kp.q1_acc, my = kp.q2_yawrate * kp.q2_yawrate * kp.q1_yawrate;
-  r.lx0 = lx0; r.lx1 = lx1; r.lx2 = lx2;
-  r.l00 = h00; r.l01 = h01; r.l11 = h11;
-  r.lu0 = (sa * e1 - sa * e2) + (2 * kp.w_acc) * u0;
-  r.lu1 = (sy * e3 - sy * e4) + (2 * kp.w_yawrate) * u1;
-  r.luu0 = ma * e1 + ma * e2 + 2 * kp.w_acc;
-  r.luu1 = my * e3 + my * e4 + 2 * kp.w_yawrate;
+  double a1, a2, a3, a4;
+  ctrl_args(kp, u0, u1, v, a1, a2, a3, a4);
+  const double e1 = exp_fast(a1);
+  const double e2 = exp_fast(a2);
+  const double e3 = exp_fast(a3);
+  const double e4 = exp_fast(a4);
+  r.lx0 = a.lx0; r.lx1 = a.lx1; r.lx2 = lx2;
+  r.l00 = a.h00; r.l01 = a.h01; r.l11 = a.h11;
+  ctrl_terms(kp, u0, u1, e1, e2, e3, e4, r);
 
   // --- A/B entries
-  const double adv = vn * dt + u0 * kp.half_dt2;
-  r.al = dt * cn;            // A(2,0)
-  r.be = dt * sn;            // A(2,1)
-  r.ga = (-1) * sn * adv;    // A(3,0)
-  r.de = cn * adv;           // A(3,1)
-  r.p = kp.half_dt2 * cn;    // B(0,0)
-  r.q = kp.half_dt2 * sn;    // B(0,1)
+  ab_terms(kp, u0, vn, cn, sn, r);
   return J;
 }
 

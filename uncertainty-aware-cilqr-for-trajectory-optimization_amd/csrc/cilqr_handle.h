@@ -74,6 +74,7 @@ struct cilqr_handle {
   int hint_B;          // batch size the order is valid for (0: none)
   void* hint_stream;   // stream it was built on (a call on another stream does not use it)
   int hint_off;        // environment CILQR_NO_SCHEDULE_HINT at create
+  int pair_off;        // environment CILQR_NO_PAIR_KERNEL at create: never the two-wavefront kernel (A/B runs, the bit-equality test)
   int force_g;       // 0 = automatic; else 1,2,4,8,16,32 or 64 (test hook: environment CILQR_FORCE_G at create)
   double* d_pair;
   // warp staging (grown on demand by the host-pointer warp entry point only)

@@ -66,6 +66,9 @@ struct SolveArgs {
   int32_t* hint_passes;  // null, or [B]: passes of each solve of THIS call, from which the next call's order is built
   int32_t B, N, M;
   uint32_t flags;
+  // 1: the batch has at most one solve per SIMD — the launcher may give every solve a second wavefront (cilqr_solve.hip,
+  // cilqr_solve_pair_kernel: the next linearisation runs behind the forward pass instead of after it)
+  int32_t pair;
   KParams kp;
   UncArgs unc;
 };

@@ -270,7 +270,7 @@ __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int
     const int cs = closest_sample(S, grid, px, py, LdsSamples{samp, grid.xf, grid.dxs});
     CILQR_SUB(1, (double)cs)
     Rec c;
-    Jpart += lin_step<true, Source::kPaired>(kp, px, py, xr[2], xr[4], xr[5], U[2 * t], U[2 * t + 1], xn[2], xn[4], xn[5], fma(grid.dxs, (double)cs, grid.xf),
+    Jpart += lin_step<true, Source::kPaired, FSMEM>(kp, px, py, xr[2], xr[4], xr[5], U[2 * t], U[2 * t + 1], xn[2], xn[4], xn[5], fma(grid.dxs, (double)cs, grid.xf),
                       samp[cs], M, src.at(t), c);
     CILQR_SUB(2, c.lx0 + c.lu0 + c.ga + Jpart)
     double* r = rec + t * RECW;
@@ -594,6 +594,9 @@ __device__ __forceinline__ void f_sunpack(FwdIn& o, const FwdS& r) {
 // the request completes; results to LDS (every lane stores the same values to the same addresses), where the next phase L reads
 // them by lanes.  Returns false if a step turned the heading by more than MAX_TURN (rotate_heading): the results are then not to
 // be used and the solve is handed to the GENERAL kernel.
+// PUBLISH (two-wavefront kernel): the second wavefront of the workgroup watches theta of the states for their arrival
+// (state_arrived below), so a state's theta is stored behind everything else of its step.
+template <bool PUBLISH = false>
 __device__ __forceinline__ bool forward_smem(const KParams& kp, int N, const double* X, const double* fwd, double* Xn, double* Un) {
   asm volatile("s_waitcnt vmcnt(0)\n\ts_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");  // L's and R's record stores → scalar loads
   FwdConst k;
@@ -617,7 +620,9 @@ __device__ __forceinline__ bool forward_smem(const KParams& kp, int N, const dou
     Un[2 * i] = u0; Un[2 * i + 1] = u1;
     const double delta = dyn_pose_loop(k, s, u0, u1, max_turn);
     double* xo = Xn + (i + 1) * XR;  // (cos/sin columns: filled by the next phase L)
-    xo[0] = s.x; xo[1] = s.y; xo[2] = s.v; xo[3] = s.th;
+    xo[0] = s.x; xo[1] = s.y;
+    if (PUBLISH) asm volatile("" ::: "memory");  // (compiler order only: the LDS executes one wavefront's stores in order)
+    xo[2] = s.v; xo[3] = s.th;
     // the rotation last: its ≈ 100 ticks cover the latency of the stores above, which the next step's s_waitcnt lgkmcnt(0) —
     // the only safe wait with scalar loads in flight — would otherwise pay
     rotate_heading(k, delta, s.s, s.c);
@@ -678,6 +683,7 @@ __device__ __forceinline__ void forward_general(const KParams& kp, int N, const 
 }
 
 // Nominal rollout (I/iLQR.cpp:51-62) on the in-loop sincos; false ⇒ hand over to the GENERAL kernel.
+template <bool PUBLISH = false>
 __device__ __forceinline__ bool rollout_fast(const KParams& kp, int N, const double* x0, const double* U, double* X) {
   FwdConst k;
   make_fwd_const(k, kp);
@@ -689,7 +695,14 @@ __device__ __forceinline__ bool rollout_fast(const KParams& kp, int N, const dou
   store_state(X, 0, s);  // (every lane holds the same values and stores them to the same addresses: no EXEC change)
   for (int i = 0; i < N; ++i) {
     dyn_step_loop(k, s, U[2 * i], U[2 * i + 1], max_turn);
-    store_state(X, i + 1, s);
+    if (PUBLISH) {  // theta last (forward_smem)
+      double* r = X + (i + 1) * XR;
+      r[0] = s.x; r[1] = s.y; r[4] = s.c; r[5] = s.s;
+      asm volatile("" ::: "memory");
+      r[2] = s.v; r[3] = s.th;
+    } else {
+      store_state(X, i + 1, s);
+    }
   }
   return th0_ok && max_turn <= MAX_TURN;
 }
@@ -976,6 +989,315 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
 #undef CILQR_STAMP
 }
 
+// ==== Two wavefronts per solve (BASELINE config 2 and every batch of at most one solve per SIMD) ==================================
+// The serial phases R and F of the kernel above run at the issue rate of a lone wavefront, and phase L — lanes = timesteps — can
+// only start when F has produced the whole new trajectory: a pass is R + F + L (config 2: 19 k + 19 k + 8 k ticks).  Here a solve
+// is a workgroup of TWO wavefronts (the dispatcher places them on two SIMDs of one CU: tools/ubench_wave_place.hip):
+//   wavefront 0 ("main") runs the rollout, R and F exactly as above;
+//   wavefront 1 ("aux")  linearises the NEW trajectory while F is still producing it: step t can be linearised as soon as
+//                        states t and t + 1 are in LDS, so the aux wavefront takes the horizon in chunks of 16 steps, four lanes
+//                        per step (linearize_quads), each chunk as soon as its last state has arrived, and only the last chunk
+//                        (two steps at N = 50) is still to do when F ends.
+// Arrival of a state is seen in the data itself: before a rollout or forward pass starts, theta of every state it is going to
+// write is set to a signalling-NaN bit pattern, which no arithmetic result can have (a computed NaN is quiet); F stores theta
+// last (forward_smem<PUBLISH>), one wavefront's LDS stores execute in order, so "theta of state k is not the pattern" means
+// states 0..k and controls 0..k-1 are there.  No flag stores on F's chain.  The two wavefronts meet at two barriers per pass: B1
+// behind R (main: "records consumed, F starts"; carries main's decision to go on or stop) and B2 behind F (aux: "records, J and
+// forward-pass rows of the new trajectory are complete").  Main never waits inside a phase; aux only waits for stores that main
+// is certain to make (every rollout / forward pass runs to its end), and a bounded poll count turns a broken promise into a
+// hand-over to the GENERAL kernel instead of a hang.
+// Same bits as the one-wavefront kernel (tests: test_pair_kernel_equals_single_wavefront_kernel): the quad mapping evaluates the
+// statements of lin_step piece by piece (cilqr_device.hpp), sums a step's obstacle entries in entry order, and sums J over the
+// steps in the order of wave_sum_uniform.
+constexpr unsigned long long THETA_PENDING = 0x7FF00000DEADBEEFull;
+constexpr int PAIR_CTL = 4;       // doubles: {J of the trajectory in LDS, command | abort (two int32), -, -}
+constexpr int PAIR_SPIN = 1 << 16;  // polls (≈ 150 ticks each) before the aux wavefront gives up on a state: ≫ any phase
+constexpr int CMD_GO = 1, CMD_EXIT = 2;
+
+template <int K>
+__device__ __forceinline__ double quad_bcast(double v) {  // lane K of every quad to its four lanes (DPP quad_perm [K, K, K, K])
+  return dpp_f64<K * 0x55>(v);
+}
+template <int K>
+__device__ __forceinline__ int quad_bcast_i(int v) { return __builtin_amdgcn_update_dpp(v, v, K * 0x55, 0xF, 0xF, false); }
+
+// Waits until state k of the trajectory in X has arrived (see above).  false: gave up.
+__device__ __forceinline__ bool state_arrived(const double* X, int k, int& budget) {
+  const volatile unsigned long long* p = reinterpret_cast<const volatile unsigned long long*>(X + k * XR + 3);
+  while (*p == THETA_PENDING) {
+    if (--budget < 0) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  asm volatile("" ::: "memory");  // the reads of the state lie behind the poll
+  return true;
+}
+__device__ __forceinline__ void mark_pending(double* X, int N, int first_lane, int stride) {
+  for (int t = 1 + first_lane; t <= N; t += stride) reinterpret_cast<unsigned long long*>(X + t * XR + 3)[0] = THETA_PENDING;
+}
+
+// Phase L of the two-wavefront kernel: one wavefront, lanes = 16 steps × 4; chunk c as soon as state min(16c + 16, N) is there.
+// Writes the records, the forward-pass rows {x, y, v, theta, u0, u1} of the old trajectory, J per step and the sum J → ctl[0].
+// false: a state did not arrive within the poll budget (ctl's abort word is set; the results are not to be used).
+__device__ __forceinline__ bool linearize_quads(const KParams& kp, int N, int M, int lane, const double* samp, int S,
+                                                const SampleGrid& grid, const double* X, const double* U, double* rec,
+                                                const double* tab, const double* wts, double* fwd, double* Jt, double* ctl) {
+  const int sub = lane & 3;
+  int budget = PAIR_SPIN;
+  bool ok = true;
+  const LdsSamples at{samp, grid.xf, grid.dxs};
+  for (int t0 = 0; t0 < N; t0 += 16) {
+    if (ok) ok = state_arrived(X, min(t0 + 16, N), budget);
+    const int t = t0 + (lane >> 2);
+    const bool act = t < N;
+    const int tc = act ? t : N - 1;  // (lanes past the horizon repeat the last step and store nothing)
+    const double* xr = X + tc * XR;
+    const double* xn = X + (tc + 1) * XR;
+    const double px = xr[0], py = xr[1], v = xr[2], th = xr[3], vn = xn[2], thn = xn[3];
+    const double u0 = U[2 * tc], u1 = U[2 * tc + 1];
+    // cos / sin of both headings: lanes 0, 1 of a quad evaluate theta_t, lanes 2, 3 theta_{t+1} (one sincos per lane)
+    double sA, cA;
+    sincos_loop(sub < 2 ? th : thn, sA, cA);
+    const double ct = quad_bcast<0>(cA), st = quad_bcast<0>(sA), cn = quad_bcast<2>(cA), sn = quad_bcast<2>(sA);
+    if (act && sub == 0) {  // the next forward pass reads the old state and control of step t through the scalar path
+      double2* q = reinterpret_cast<double2*>(fwd + t * FREC + 10);
+      q[0] = make_double2(px, py);
+      q[1] = make_double2(v, th);
+      q[2] = make_double2(u0, u1);
+    }
+    // closest path sample: the window of closest_sample, its candidates dealt round-robin to the quad, then the lexicographic
+    // minimum of (distance, index) over the quad — the strict-< first minimum of the ascending scan (I/Constraints.cpp:43-56)
+    int lo, hi;
+    closest_window(S, grid, px, py, at, lo, hi);
+    double md = __builtin_huge_val();
+    int best = 0x7fffffff;
+    int s = lo + sub;
+    if (sub == 0) { md = sample_dist(at, lo, px, py); best = lo; s += 4; }
+    for (; s <= hi; s += 4) {
+      const double d = sample_dist(at, s, px, py);
+      if (d < md) { md = d; best = s; }
+    }
+    if (sub == 0 && md != md) md = -__builtin_huge_val();  // (a NaN first distance keeps the first sample, as in the scan)
+    {
+      double od = dpp_f64<0xB1>(md);
+      int ob = __builtin_amdgcn_update_dpp(best, best, 0xB1, 0xF, 0xF, false);
+      bool take = od < md || (od == md && ob < best);
+      md = take ? od : md; best = take ? ob : best;
+      od = dpp_f64<0x4E>(md);
+      ob = __builtin_amdgcn_update_dpp(best, best, 0x4E, 0xF, 0xF, false);
+      take = od < md || (od == md && ob < best);
+      best = take ? ob : best;
+    }
+    const double cx = fma(grid.dxs, (double)best, grid.xf), cy = samp[best];
+    // tracking cost, as lin_step forms it
+    const double dx = px - cx, dy = py - cy, dv = v - kp.desired_speed;
+    StepSums a;
+    a.lx0 = (2 * kp.w_pos) * dx;
+    a.lx1 = (2 * kp.w_pos) * dy;
+    Rec c;
+    c.lx2 = (2 * kp.w_vel) * dv;
+    a.h00 = kp.w_pos * 2; a.h01 = 0.0; a.h11 = kp.w_pos * 2;
+    const double J = stage_cost(kp, dx, dy, dv, u0, u1);
+    // obstacles: lane `sub` of the quad evaluates entries sub, sub + 4, …; their terms join the sums in entry order
+    const ObsConsts oc = make_obs_consts(kp, px, py, ct, st);
+    for (int m0 = 0; m0 < M; m0 += 4) {
+      const int m = min(m0 + sub, M - 1);
+      const double2* pe = reinterpret_cast<const double2*>(tab + ((size_t)m * N + tc) * TABF);
+      const double2 ea = pe[0], eb = pe[1], ec = pe[2];
+      const ObsEntry e{ea.x, ea.y, eb.x, eb.y, ec.x, ec.y};
+      const double w = wts ? wts[m] : kp.w_obstacle;
+      ObsPrep p;
+      obs_prep(oc, e, p);
+      const bool need = m0 + sub < M && obs_needed(p);
+      ObsTerms g{0.0, 0.0, 0.0, 0.0, 0.0};
+      if (__builtin_amdgcn_ballot_w64(need) != 0) g = obs_terms(oc, e, p);
+      const double we = need ? w : 0.0;  // (lin_step<…, LANE_EXACT>: a step that does not need the entry adds exactly nothing)
+      obs_accumulate(a, ObsTerms{quad_bcast<0>(g.gx), quad_bcast<0>(g.gy), quad_bcast<0>(g.gxx), quad_bcast<0>(g.gxy), quad_bcast<0>(g.gyy)}, quad_bcast<0>(we));
+      if (m0 + 1 < M) obs_accumulate(a, ObsTerms{quad_bcast<1>(g.gx), quad_bcast<1>(g.gy), quad_bcast<1>(g.gxx), quad_bcast<1>(g.gxy), quad_bcast<1>(g.gyy)}, quad_bcast<1>(we));
+      if (m0 + 2 < M) obs_accumulate(a, ObsTerms{quad_bcast<2>(g.gx), quad_bcast<2>(g.gy), quad_bcast<2>(g.gxx), quad_bcast<2>(g.gxy), quad_bcast<2>(g.gyy)}, quad_bcast<2>(we));
+      if (m0 + 3 < M) obs_accumulate(a, ObsTerms{quad_bcast<3>(g.gx), quad_bcast<3>(g.gy), quad_bcast<3>(g.gxx), quad_bcast<3>(g.gxy), quad_bcast<3>(g.gyy)}, quad_bcast<3>(we));
+    }
+    // control cost: one of its four exponentials per lane of the quad
+    double a1, a2, a3, a4;
+    ctrl_args(kp, u0, u1, v, a1, a2, a3, a4);
+    const double ee = exp_fast(sub == 0 ? a1 : sub == 1 ? a2 : sub == 2 ? a3 : a4);
+    c.lx0 = a.lx0; c.lx1 = a.lx1;
+    c.l00 = a.h00; c.l01 = a.h01; c.l11 = a.h11;
+    ctrl_terms(kp, u0, u1, quad_bcast<0>(ee), quad_bcast<1>(ee), quad_bcast<2>(ee), quad_bcast<3>(ee), c);
+    ab_terms(kp, u0, vn, cn, sn, c);
+    if (act && sub == 0) {
+      double* r = rec + t * RECF;
+      const double ih = 2.0 / kp.dt;  // production records: acceleration in units of (dt/2)·u0 (riccati_mfma)
+      r[0] = c.lx0; r[1] = c.lx1; r[2] = c.lx2; r[3] = c.l00; r[4] = c.l01; r[5] = c.l11;
+      r[6] = c.lu0 * ih; r[7] = c.lu1; r[8] = c.luu0 * (ih * ih); r[9] = c.luu1;
+      r[10] = c.al; r[11] = c.be; r[12] = c.ga; r[13] = c.de;
+      Jt[t] = J;
+    }
+  }
+  // J = sum over the steps, in the order of the one-wavefront kernel: lanes = steps (t, t + 64, …), then wave_sum_uniform
+  double part = 0.0;
+  for (int t = lane; t < N; t += WAVE) part += Jt[t];
+  const double J = wave_sum_uniform(part);
+  if (lane == 0) {
+    ctl[0] = J;
+    if (!ok) reinterpret_cast<int*>(ctl + 1)[1] = 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the forward-pass rows have reached L2 before the barrier that follows
+  return ok;
+}
+
+// LDS: the compact layout of cilqr_solve_kernel (samp, X, U, rec, cst, tab), then J per step and the control block.
+template <bool DIAG>
+__global__ __launch_bounds__(2 * WAVE) void cilqr_solve_pair_kernel(SolveArgs a) {
+  unsigned long long tk0 = 0, tk = 0, c_pro = 0, c_L = 0, c_R = 0, c_F = 0, n_L = 0, n_R = 0;
+  unsigned long long sub[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (DIAG) tk0 = tk = __builtin_readcyclecounter();
+#define CILQR_STAMP(acc)                                 \
+  if (DIAG) {                                            \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    acc += now_ - tk;                                    \
+    tk = now_;                                           \
+  }
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  if ((int)blockIdx.x >= a.B) return;
+  const int b = __builtin_amdgcn_readfirstlane(a.order ? a.order[blockIdx.x] : (int)blockIdx.x);
+  if (b >= a.B) return;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const KParams kp = a.kp;
+  const int N = a.N, M = a.M, S = kp.n_samples;
+  double* samp = lds;
+  double* Xa = samp + ((S + 1) & ~1);
+  double* Ua = Xa + (N + 1) * XR;
+  double* rec = Ua + 2 * N;
+  double* cst = rec + N * RECF;
+  double* tab = cst + RCST;
+  double* Jt = tab + (size_t)M * TABF * N;
+  double* ctl = Jt + ((N + 1) & ~1);
+  double* fwd = a.fwd + (size_t)b * (N + 1) * FREC;
+  int* const cmd = reinterpret_cast<int*>(ctl + 1);  // [0] command, [1] abort
+
+  // ---- prologue, both wavefronts -----------------------------------------------------------------------------------
+  SampleGrid grid;
+  make_sample_grid(grid, a.xplan_fl[2 * b], a.xplan_fl[2 * b + 1], S);
+  {
+    const double* pc = a.poly + (size_t)b * CILQR_POLY_COEFFS;
+    for (int s = tid; s < S; s += 2 * WAVE) {
+      double xs;
+      sample_xy(grid, pc, s, xs, samp[s]);
+    }
+  }
+  const double* Ug = a.U + (size_t)b * 2 * N;
+  for (int i = tid; i < 2 * N; i += 2 * WAVE) Ua[i] = Ug[i];
+  if (tid < 16 && (tid & 7) < 5) cst[(tid & 7) + (tid >> 3) * RECF] = (tid & 7) == 0 ? 0.0 : (tid & 7) == 1 ? 1.0 : (tid & 7) == 2 ? kp.dt : (tid & 7) == 3 ? kp.w_vel * 2 : 2.0;
+  const double* wts = a.obs_weight ? a.obs_weight + (size_t)b * M : nullptr;
+  for (int m = wave; m < M; m += 2) {  // obstacle table, I/Obstacle.cpp:41-62
+    for (int t = lane; t < N; t += WAVE) {
+      const ObsEntry e = make_obs_entry(kp, a.obs_pose + (((size_t)b * M + m) * N + t) * 4, a.obs_dim + (((size_t)b * M + m) * N + t) * 2);
+      double* o = tab + ((size_t)m * N + t) * TABF;
+      o[0] = e.ox; o[1] = e.oy; o[2] = e.co; o[3] = e.so; o[4] = e.ia2; o[5] = e.ib2;
+    }
+  }
+  mark_pending(Xa, N, tid, 2 * WAVE);
+  if (tid == 0) { cmd[0] = 0; cmd[1] = 0; }
+  __syncthreads();
+
+  if (wave != 0) {
+    // ---- the aux wavefront -------------------------------------------------------------------------------------------
+    {  // largest step between adjacent path samples in y: closest_sample's second window (cilqr_device.hpp)
+      double m = 0.0;
+      for (int q = lane; q + 1 < S; q += WAVE) {
+        const double d = fabs(samp[q + 1] - samp[q]);
+        m = fmax(m, d == d ? d : __builtin_huge_val());
+      }
+      grid.dmax = wave_max_uniform(m);
+    }
+    for (;;) {
+      linearize_quads(KParams(phase_params()), N, M, lane, samp, S, grid, Xa, Ua, rec, tab, wts, fwd, Jt, ctl);
+      __syncthreads();  // B2: the new trajectory is linearised
+      __syncthreads();  // B1: main has decided (and, going on, has run R)
+      if (*reinterpret_cast<volatile int*>(cmd) != CMD_GO) break;
+    }
+    return;
+  }
+
+  // ---- the main wavefront ------------------------------------------------------------------------------------------------
+  bool handover = !rollout_fast<true>(kp, N, a.x0 + (size_t)b * 4, Ua, Xa);  // nominal rollout, I/iLQR.cpp:51-62
+  __syncthreads();  // B2
+  CILQR_STAMP(c_pro)
+  double J_old = DBL_MAX, lamb = 1.0, J_new = 0.0;
+  int iters = 0, status = CILQR_EXIT_MAX_ITER, n_pass = 0;
+  const int max_it = kp.max_iterations;
+  // iteration loop, I/iLQR.cpp:204-239, as in cilqr_solve_kernel (early exit at the first rejection; forward pass in place)
+  for (int it = 0; it < max_it && !handover; ++it) {
+    ++iters;
+    if (reinterpret_cast<volatile int*>(cmd)[1] != 0) { handover = true; break; }  // the aux wavefront gave up on a state
+    J_new = *reinterpret_cast<volatile double*>(ctl);
+    if (DIAG) ++n_L;
+    const bool accept = J_new < J_old;
+    if (!accept) {
+      if (J_new != J_new) { status = CILQR_EXIT_NUMERIC; break; }
+      for (;;) {
+        lamb = lamb * kp.lamb_factor;
+        if (lamb > kp.lamb_max) { status = CILQR_EXIT_LAMBDA_MAX; break; }
+        if (++it >= max_it) { status = CILQR_EXIT_MAX_ITER; break; }
+        ++iters;
+      }
+      break;
+    }
+    mark_pending(Xa, N, lane, WAVE);  // the forward pass below rewrites states 1..N; the aux wavefront sleeps at B1 meanwhile
+    CILQR_STAMP(c_L)
+    if (!riccati_mfma<true, DIAG>(N, rec, rec, fwd, cst, 2.0 / kp.dt, lamb, sub)) { handover = true; break; }
+    if (lane == 0) *reinterpret_cast<volatile int*>(cmd) = CMD_GO;
+    __syncthreads();  // B1
+    CILQR_STAMP(c_R)
+    ++n_pass;
+    if (DIAG) ++n_R;
+    const bool f_ok = forward_smem<true>(KParams(phase_params()), N, Xa, fwd, Xa, Ua);
+    CILQR_STAMP(c_F)
+    __syncthreads();  // B2
+    CILQR_STAMP(c_L)
+    if (!f_ok) { handover = true; break; }
+    lamb = lamb / kp.lamb_factor;
+    if (fabs(J_new - J_old) < kp.tolerance) {
+      status = CILQR_EXIT_TOLERANCE;
+      J_new = *reinterpret_cast<volatile double*>(ctl);  // get_J of the final trajectory
+      break;
+    }
+    J_old = J_new;
+    if (it + 1 >= max_it) J_new = *reinterpret_cast<volatile double*>(ctl);
+  }
+  if (lane == 0) *reinterpret_cast<volatile int*>(cmd) = CMD_EXIT;
+  __syncthreads();  // B1: releases the aux wavefront
+
+  int32_t* const hint = phase_args().hint_passes;
+  if (lane == 0) {
+    phase_args().redo[b] = handover ? 1 : 0;
+    if (handover && hint) hint[b] = 63;
+  }
+  if (handover) return;  // outputs (and the in/out U) untouched: the GENERAL kernel starts from the same inputs
+
+  // ---- epilogue: X_result / U_result (:243-244) ----------------------------------------------------------------
+  const SolveArgs ae = phase_args();
+  double* Uo = ae.U + (size_t)b * 2 * N;
+  for (int i = lane; i < 2 * N; i += WAVE) Uo[i] = Ua[i];
+  double* Xg = ae.X_out + (size_t)b * 4 * (N + 1);
+  for (int i = lane; i < 4 * (N + 1); i += WAVE) Xg[i] = Xa[(i >> 2) * XR + (i & 3)];
+  if (lane == 0) {
+    if (ae.J_out) ae.J_out[b] = J_new;
+    if (ae.iters_out) ae.iters_out[b] = iters;
+    if (ae.status_out) ae.status_out[b] = status;
+    if (ae.passes) ae.passes[b] = n_pass;
+    if (ae.hint_passes) ae.hint_passes[b] = n_pass;
+  }
+  if (DIAG && lane == 0 && a.diag) {
+    const unsigned long long now_ = __builtin_readcyclecounter();
+    unsigned long long* o = a.diag + (size_t)b * DIAG_SLOTS;
+    o[0] = c_pro; o[1] = c_L; o[2] = c_R; o[3] = c_F; o[4] = now_ - tk; o[5] = n_L; o[6] = n_R; o[7] = now_ - tk0;
+    for (int q = 0; q < 8; ++q) o[8 + q] = sub[q];
+  }
+#undef CILQR_STAMP
+}
+
 __global__ void quu_inverse_kernel(int n, const double* q, const double* lamb, double* out, int general) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -1027,6 +1349,15 @@ hipError_t launch_pair_unc(const SolveArgs& a, size_t extra, hipStream_t stream)
   }
   hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, TAB, false, UNC>), dim3(a.B), dim3(WAVE), lds_fast, stream, a);
   hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, TAB, true, UNC>), dim3(a.B), dim3(WAVE), lds_general, stream, a);
+  return hipGetLastError();
+}
+// The two-wavefront kernel (table in LDS, no map, early exit) with the GENERAL kernel of the one-wavefront family behind it.
+template <bool DIAG>
+hipError_t launch_two_wavefronts(const SolveArgs& a, size_t tab_bytes, hipStream_t stream) {
+  const size_t lds_fast = core_lds_bytes(a.N, a.kp.n_samples, true) + tab_bytes + ((((size_t)a.N + 1) & ~(size_t)1) + PAIR_CTL) * sizeof(double);
+  const size_t lds_general = core_lds_bytes(a.N, a.kp.n_samples, false) + tab_bytes;
+  hipLaunchKernelGGL((cilqr_solve_pair_kernel<DIAG>), dim3(a.B), dim3(2 * WAVE), lds_fast, stream, a);
+  hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, 1, true, false>), dim3(a.B), dim3(WAVE), lds_general, stream, a);
   return hipGetLastError();
 }
 template <bool DIAG, int TAB>
@@ -1097,6 +1428,8 @@ hipError_t launch_solve_wave(const SolveArgs& a, hipStream_t stream) {
   }
   if (lds > SOLVE_LDS_MAX) return hipErrorInvalidValue;  // checked by the caller
   const size_t extra = tab_lds ? tab_bytes : 0;
+  if (tab_lds && a.pair && !a.unc.layer && (a.flags & CILQR_FLAG_FAITHFUL_ITERS) == 0)
+    return a.diag ? launch_two_wavefronts<true>(a, tab_bytes, stream) : launch_two_wavefronts<false>(a, tab_bytes, stream);
   if (a.diag) return tab_lds ? launch_pair<true, 1>(a, extra, stream) : launch_pair<true, 0>(a, extra, stream);
   return tab_lds ? launch_pair<false, 1>(a, extra, stream) : launch_pair<false, 0>(a, extra, stream);
 }
