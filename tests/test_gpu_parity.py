@@ -414,12 +414,12 @@ def test_several_wavefronts_per_simd(cilqr, oracle, B, N, M):
 
 
 def _pair_vs_single(cilqr, monkeypatch, sc, N, M, B):
-    """The same batch on a handle that may use the two-wavefront kernel and on one created with CILQR_NO_PAIR_KERNEL."""
+    """The same batch on a handle created with CILQR_PAIR_KERNEL (the two-wavefront kernel, an opt-in experiment) and on an ordinary one."""
     p = cilqr.default_params(N)
+    monkeypatch.setenv("CILQR_PAIR_KERNEL", "1")
     two = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=max(M, 1), device=0)
-    monkeypatch.setenv("CILQR_NO_PAIR_KERNEL", "1")
+    monkeypatch.delenv("CILQR_PAIR_KERNEL")
     one = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=max(M, 1), device=0)
-    monkeypatch.delenv("CILQR_NO_PAIR_KERNEL")
     try:
         return _gpu_batch(two, sc), _gpu_batch(one, sc)
     finally:
@@ -429,17 +429,16 @@ def _pair_vs_single(cilqr, monkeypatch, sc, N, M, B):
 
 @pytest.mark.parametrize("N,M,B", [(50, 4, 1024), (30, 2, 200), (2, 1, 9), (3, 0, 5), (17, 5, 64), (64, 4, 96), (72, 3, 40), (33, 9, 70)])
 def test_pair_kernel_equals_single_wavefront_kernel(cilqr, oracle, monkeypatch, N, M, B):
-    """Up to one solve per SIMD every solve runs as a workgroup of two wavefronts (cilqr_solve_pair_kernel: the linearisation of
-    the new trajectory runs on the second wavefront behind the forward pass, four lanes per step).  It must return the bits of
-    the one-wavefront kernel — U, X, J, iteration counts, exits — on config 2 in full and on ragged shapes: horizons that are no
-    multiple of the 16-step chunks, obstacle counts that are no multiple of the quad, none at all, N > 64; and both must agree
-    with the oracle."""
+    """CILQR_PAIR_KERNEL (opt-in experiment): up to one solve per SIMD every solve runs as a workgroup of two
+    wavefronts — the linearisation of the new trajectory on the second one, behind the forward pass, four lanes per step.  Same
+    statements, other order of a few sums: it must take the accept / reject path of the one-wavefront kernel on every solve and
+    agree with it to rounding (1e-11) — on config 2 in full and on ragged shapes: horizons that are no multiple of its chunks,
+    obstacle counts that are no multiple of the quad, none at all, N > 64 — and both must agree with the oracle."""
     from cilqr_amd import scenes
     p = cilqr.default_params(N)
     sc = scenes.make_static(B, N, M, p, 7100 + N)
     got, ref = _pair_vs_single(cilqr, monkeypatch, sc, N, M, B)
-    for k in ("iters", "status", "U", "X", "J"):
-        assert np.array_equal(got[k], ref[k]), "%s differs in %d solves" % (k, int(np.any(np.atleast_2d(got[k].T != ref[k].T), axis=0).sum()))
+    _compare(got, ref, 1e-11, "two wavefronts against one")
     idx = np.arange(min(B, 128))
     sub = {k: (v[idx] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in sc.items()}
     _compare({k: v[idx] for k, v in got.items()}, _oracle_batch(oracle, N, sub), TIGHT, "two wavefronts per solve")
@@ -448,7 +447,7 @@ def test_pair_kernel_equals_single_wavefront_kernel(cilqr, oracle, monkeypatch, 
 def test_pair_kernel_weights_warm_starts_and_hand_over(cilqr, oracle, monkeypatch):
     """The two-wavefront kernel with per-obstacle weights, warm-started (random) controls, moving obstacles, and solves that it
     hands to the GENERAL kernel (a NaN start, a heading beyond the in-loop sincos range, a turn of more than 1/4 rad per step):
-    the bits of the one-wavefront kernel, and the oracle's results where it has finite ones."""
+    the accept / reject paths of the one-wavefront kernel, and the oracle's results where it has finite ones."""
     from cilqr_amd import scenes
     N, M, B = 50, 6, 160
     p = cilqr.default_params(N)
@@ -465,8 +464,8 @@ def test_pair_kernel_weights_warm_starts_and_hand_over(cilqr, oracle, monkeypatc
     sc["x0"][7, 2] = 25.0
     sc["U"][7, 1::2] = 5.0  # full lock at 25 m/s: more than 1/4 rad per step
     got, ref = _pair_vs_single(cilqr, monkeypatch, sc, N, M, B)
-    for k in ("iters", "status", "U", "X", "J"):
-        assert np.array_equal(got[k], ref[k], equal_nan=True), k
+    assert np.array_equal(got["iters"], ref["iters"]) and np.array_equal(got["status"], ref["status"])
+    assert np.array_equal(np.isnan(got["U"]), np.isnan(ref["U"]))
     keep = np.ones(B, bool)
     keep[[3]] = False
     sub = {k: (v[keep] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in sc.items()}

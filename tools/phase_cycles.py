@@ -6,6 +6,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "uncertainty-aware-cilqr-for-trajectory
 import numpy as np, torch
 import cilqr_amd
 from cilqr_amd import scenes
+FLAGS = int(os.environ.get("FLAGS", 0))
 B, N, M = int(os.environ.get("B", 1024)), int(os.environ.get("N", 50)), int(os.environ.get("M", 4))
 p = cilqr_amd.default_params(N)
 sc = scenes.make_static(B, N, M, p, scenes.SEED0 + 2)
@@ -24,13 +25,13 @@ for _ in range(2):  # second run timed (same stamped kernel)
     torch.cuda.synchronize()
     e0.record()
     s.solve_batch_device(torch.cuda.current_stream().cuda_stream, B, N, M, x0.data_ptr(), U.data_ptr(), poly.data_ptr(), xpl.data_ptr(), pose.data_ptr() if M else 0,
-                         dim.data_ptr() if M else 0, 0, X.data_ptr(), J.data_ptr(), it.data_ptr(), st.data_ptr())
+                         dim.data_ptr() if M else 0, 0, X.data_ptr(), J.data_ptr(), it.data_ptr(), st.data_ptr(), FLAGS)
     e1.record()
     torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
 U.copy_(U0)
 s.solve_batch_device(0, B, N, M, x0.data_ptr(), U.data_ptr(), poly.data_ptr(), xpl.data_ptr(), pose.data_ptr() if M else 0,
-                     dim.data_ptr() if M else 0, 0, X.data_ptr(), J.data_ptr(), it.data_ptr(), st.data_ptr())
+                     dim.data_ptr() if M else 0, 0, X.data_ptr(), J.data_ptr(), it.data_ptr(), st.data_ptr(), FLAGS)
 torch.cuda.synchronize()
 d = diag.cpu().numpy().astype(np.float64)
 nL, nR = d[:, 5], d[:, 6]
@@ -44,7 +45,11 @@ print("R per call: %.0f -> %.0f per step" % ((d[m, 2] / nR[m]).mean(), (d[m, 2] 
 print("F per call: %.0f -> %.0f per step" % ((d[m, 3] / nR[m]).mean(), (d[m, 3] / nR[m]).mean() / N))
 w = int(np.argmax(d[:, 7]))
 print("slowest solve %d: pro %d L %d R %d F %d epi %d nL %d nR %d total %d" % ((w,) + tuple(int(v) for v in d[w][:8])))
-if d[:, 8:].sum() > 0:  # sub-phase stamps (one-wavefront-per-solve family)
+if os.environ.get("PAIR"):  # two-wavefront kernel: slots 8..11 are the aux wavefront's account
+    k = d[:, 11]
+    print("aux wavefront, ticks per linearisation: waiting for states %.0f | chunk work %.0f | from the last state's arrival to its barrier %.0f  (calls mean %.1f)"
+          % ((d[:, 8] / k).mean(), (d[:, 9] / k).mean(), (d[:, 10] / k).mean(), k.mean()))
+elif d[:, 8:].sum() > 0:  # sub-phase stamps (one-wavefront-per-solve family)
     names = ["cos/sin columns", "closest sample (+ forward-record stores)", "cost derivatives (lin_step)", "record stores (+ map term)", "cost reduction"]
     print("inside L, ticks per call:  " + "  ".join("%s %.0f" % (n, (d[:, 8 + i] / nL).mean()) for i, n in enumerate(names)))
     names = ["P, Db, Da + readlanes", "determinant + reciprocal", "Dk, H, Dv, copies, stores"]

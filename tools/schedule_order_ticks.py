@@ -51,8 +51,10 @@ def sequence(kind, B, ticks, N=50, M=4):
             pose, dim, off = dv(i["nom_pose"]), dv(i["nom_dim"]), dv(i["offsets"])
         else:
             pose, dim = dv(i["obs_pose"]), dv(i["obs_dim"])
-        ms, Us = [], []
-        for k, slv in enumerate((hinted, plain)):
+        ms, Us = [None, None], [None, None]
+        # the two handles take turns in going first (whoever runs second finds the tick's inputs in the caches)
+        for k in ((0, 1) if t % 2 == 0 else (1, 0)):
+            slv = (hinted, plain)[k]
             U = U0.clone()
             torch.cuda.synchronize()
             e0.record()
@@ -65,8 +67,8 @@ def sequence(kind, B, ticks, N=50, M=4):
                                        dim.data_ptr(), 0, X[k].data_ptr(), J[k].data_ptr(), it[k].data_ptr(), st[k].data_ptr())
             e1.record()
             torch.cuda.synchronize()
-            ms.append(e0.elapsed_time(e1))
-            Us.append(U)
+            ms[k] = e0.elapsed_time(e1)
+            Us[k] = U
         assert torch.equal(Us[0], Us[1]) and torch.equal(X[0], X[1]) and torch.equal(it[0], it[1]), "dispatch order changed a result"
         ps = passes.cpu().numpy().copy()
         # how well the previous tick's pass counts predict this tick's (what the hint relies on)
@@ -79,6 +81,9 @@ def sequence(kind, B, ticks, N=50, M=4):
     hinted.close()
     plain.close()
     a = np.array([(r[1], r[2]) for r in rows[1:]])  # tick 0 has no hint yet
+    first = np.array([(r[1], r[2]) for r in rows[1:] if r[0] % 2 == 0]), np.array([(r[1], r[2]) for r in rows[1:] if r[0] % 2 == 1])
+    print("  (hinted handle first: with %.3f / without %.3f ms; plain handle first: with %.3f / without %.3f ms)"
+          % (first[0][:, 0].mean(), first[0][:, 1].mean(), first[1][:, 0].mean(), first[1][:, 1].mean()))
     print("%s B=%d, ticks 1..%d: with hint %.3f ms mean (%.2f M solves/s) | without %.3f ms mean (%.2f M solves/s) | first tick %.3f ms"
           % (kind, B, ticks - 1, a[:, 0].mean(), B / a[:, 0].mean() / 1e3, a[:, 1].mean(), B / a[:, 1].mean() / 1e3, rows[0][1]), flush=True)
 

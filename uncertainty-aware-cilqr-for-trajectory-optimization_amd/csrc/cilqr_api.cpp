@@ -99,9 +99,10 @@ static int launch_wave_scheduled(cilqr_handle* h, cilqr::SolveArgs& a, void* str
   const bool hinted = !h->hint_off && a.B > h->simds;
   a.order = hinted && h->hint_B == a.B && h->hint_stream == stream ? h->d_order : nullptr;
   a.hint_passes = hinted ? h->d_hint_passes : nullptr;
-  // up to one solve per SIMD every solve can have a second wavefront on another SIMD of its CU (cilqr_solve_pair_kernel); with
-  // more solves than SIMDs the second wavefronts would take the register space of solves waiting to start
-  a.pair = !h->pair_off && a.B <= h->simds ? 1 : 0;
+  // CILQR_PAIR_KERNEL: up to one solve per SIMD every solve gets a second wavefront on another SIMD of its CU that linearises the
+  // new trajectory behind the forward pass (cilqr_solve_pair_kernel).  Measured slower at every batch size (the
+  // second wavefront's work is paid for by the main wavefronts that share its SIMD): an experiment, not the default.
+  a.pair = h->pair_on && a.B <= h->simds ? 1 : 0;
   HIP_TRY(cilqr::launch_solve_wave(a, (hipStream_t)stream));
   if (hinted) {
     HIP_TRY(cilqr::launch_schedule_order(h->d_hint_passes, a.B, h->d_order, (hipStream_t)stream));
@@ -211,7 +212,7 @@ int cilqr_create(const cilqr_params* p, int max_batch, int max_horizon, int max_
   if (err == hipSuccess) err = dmalloc(&h->d_order, B);
   h->hint_B = 0; h->hint_stream = nullptr;
   h->hint_off = getenv("CILQR_NO_SCHEDULE_HINT") != nullptr;
-  h->pair_off = getenv("CILQR_NO_PAIR_KERNEL") != nullptr;
+  h->pair_on = getenv("CILQR_PAIR_KERNEL") != nullptr;
   if (err == hipSuccess) err = dmalloc(&h->d_pair, (size_t)2);
   if (err == hipSuccess) err = dmalloc(&h->d_triple, (size_t)3);
   if (err == hipSuccess) err = dmalloc(&h->d_gather, (size_t)3);

@@ -314,7 +314,9 @@ __device__ __forceinline__ double sample_dist(SampleAt at, int s, double px, dou
 }
 
 // The index window [lo, hi] that contains the argmin (see closest_sample): one statement of it for every search.
-template <typename SampleAt>
+// YSIDE = false leaves out the second (y-side) window: still a superset of the argmin's neighbourhood, i.e. the same argmin; worth
+// it where the scan is dealt to several lanes and the window's square root and division cost more than the candidates they save.
+template <bool YSIDE = true, typename SampleAt>
 __device__ __forceinline__ void closest_window(int S, const SampleGrid& g, double px, double py, SampleAt at, int& lo, int& hi) {
   auto dist = [&](int s) { return sample_dist(at, s, px, py); };
   lo = 0;
@@ -337,7 +339,7 @@ __device__ __forceinline__ void closest_window(int S, const SampleGrid& g, doubl
       // the y-bound stays non-negative across the whole first window (D·hw ≤ Ly) and c really is the sample nearest in x
       // (e ≤ h); widened by a 1e-9 relative margin and two samples, like the first window ≫ any rounding in its terms.
       const double h = fabs(g.dxs), D = g.dmax, e = fabs(scx - px), Ly = fabs(scy - py);
-      if (D * hw <= Ly && e <= h) {
+      if (YSIDE && D * hw <= Ly && e <= h) {
         const double A = h * h + D * D, Bq = h * e + Ly * D;
         const double T = dc * (1.0 + 1.0e-9);
         const double disc = Bq * Bq + A * (T - e * e - Ly * Ly);

@@ -580,8 +580,14 @@ __device__ __forceinline__ void f_sload_first(FwdS& r, const double* p) {
 __device__ __forceinline__ void f_sload_next(FwdS& r, const double* p) {
   asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "+s"(r.lo), "+s"(r.hi) : "s"(p) : "memory");
 }
+// The wait is the compiler's own s_waitcnt (the builtin), not text inside the assembly statement: hipcc's wait-count pass then
+// KNOWS that no LDS store of an earlier step is pending behind this point.  With the wait hidden in assembly text it protected the
+// data registers of those stores itself where it saw fit — in the two-wavefront kernel with an s_waitcnt lgkmcnt(1) in the middle
+// of the step, which (the scalar loads, invisible to it, being in flight there) stalled every step on the record it had just
+// requested: F 372 → 504 ticks per step.  The empty assembly statement behind it carries the registers, as before.
 __device__ __forceinline__ void f_swait(FwdS& r) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.lo), "+s"(r.hi) : : "memory");
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+  asm volatile("" : "+s"(r.lo), "+s"(r.hi) : : "memory");
 }
 __device__ __forceinline__ void f_sunpack(FwdIn& o, const FwdS& r) {
   o.g[0] = r.lo[0]; o.g[1] = r.lo[1]; o.g[2] = r.lo[2]; o.g[3] = r.lo[3]; o.g[4] = r.lo[4]; o.g[5] = r.lo[5];
@@ -989,15 +995,15 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
 #undef CILQR_STAMP
 }
 
-// ==== Two wavefronts per solve (BASELINE config 2 and every batch of at most one solve per SIMD) ==================================
+// ==== Two wavefronts per solve: an experiment, OFF by default (CILQR_PAIR_KERNEL at cilqr_create switches it on) ====================
 // The serial phases R and F of the kernel above run at the issue rate of a lone wavefront, and phase L — lanes = timesteps — can
 // only start when F has produced the whole new trajectory: a pass is R + F + L (config 2: 19 k + 19 k + 8 k ticks).  Here a solve
 // is a workgroup of TWO wavefronts (the dispatcher places them on two SIMDs of one CU: tools/ubench_wave_place.hip):
 //   wavefront 0 ("main") runs the rollout, R and F exactly as above;
 //   wavefront 1 ("aux")  linearises the NEW trajectory while F is still producing it: step t can be linearised as soon as
-//                        states t and t + 1 are in LDS, so the aux wavefront takes the horizon in chunks of 16 steps, four lanes
-//                        per step (linearize_quads), each chunk as soon as its last state has arrived, and only the last chunk
-//                        (two steps at N = 50) is still to do when F ends.
+//                        states t and t + 1 are in LDS, so the aux wavefront takes the horizon in chunks of up to 16 steps, four
+//                        lanes per step (linearize_quads), each chunk as soon as its last state has arrived, and only the last
+//                        chunk is still to do when F ends.
 // Arrival of a state is seen in the data itself: before a rollout or forward pass starts, theta of every state it is going to
 // write is set to a signalling-NaN bit pattern, which no arithmetic result can have (a computed NaN is quiet); F stores theta
 // last (forward_smem<PUBLISH>), one wavefront's LDS stores execute in order, so "theta of state k is not the pattern" means
@@ -1006,13 +1012,21 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
 // forward-pass rows of the new trajectory are complete").  Main never waits inside a phase; aux only waits for stores that main
 // is certain to make (every rollout / forward pass runs to its end), and a bounded poll count turns a broken promise into a
 // hand-over to the GENERAL kernel instead of a hang.
-// Same bits as the one-wavefront kernel (tests: test_pair_kernel_equals_single_wavefront_kernel): the quad mapping evaluates the
-// statements of lin_step piece by piece (cilqr_device.hpp), sums a step's obstacle entries in entry order, and sums J over the
-// steps in the order of wave_sum_uniform.
+// MEASURED (round 3, profiles/r03_pair_kernel_ab.txt; tools/pair_ab.py, tools/phase_cycles.py with PAIR=1): it does not pay.
+// A chunk of 16 steps costs the aux wavefront ≈ 4.3 k ticks — the linearisation of a step is one dependent chain (sincos → search
+// window → scan → barrier exponentials → sums) that four lanes shorten only from 6.9 k to 4.3 k — so what main still waits for
+// behind F is ≈ 6.4 k ticks instead of the 8.2 k of phase L; F itself goes from 372 to 392 ticks per step with the aux on
+// another SIMD of its CU and to 424 once other solves' aux wavefronts share its SIMD (B = 1024: every SIMD holds one main and one
+// aux, and a SIMD that issues for one does not issue for the other); launches: B = 64 0.406 against 0.390 ms, 256 0.410 / 0.407,
+// 512 0.439 / 0.412, 1024 0.474 / 0.418.  Kept, with its tests, as the record of that A/B.
+// Results: the statements of lin_step piece by piece (cilqr_device.hpp), a step's obstacle entries summed in entry order, J
+// summed in the order of wave_sum_uniform — agreement with the one-wavefront kernel to rounding (observed ≤ 4e-13 on config 2;
+// the compiler contracts a few sums differently in the two mappings), accept / reject paths equal on every solve tested.
 constexpr unsigned long long THETA_PENDING = 0x7FF00000DEADBEEFull;
 constexpr int PAIR_CTL = 4;       // doubles: {J of the trajectory in LDS, command | abort (two int32), -, -}
 constexpr int PAIR_SPIN = 1 << 16;  // polls (≈ 150 ticks each) before the aux wavefront gives up on a state: ≫ any phase
 constexpr int CMD_GO = 1, CMD_EXIT = 2;
+constexpr int PAIR_LAST = 10;  // steps of the last chunk of a linearisation (linearize_quads)
 
 template <int K>
 __device__ __forceinline__ double quad_bcast(double v) {  // lane K of every quad to its four lanes (DPP quad_perm [K, K, K, K])
@@ -1022,11 +1036,14 @@ template <int K>
 __device__ __forceinline__ int quad_bcast_i(int v) { return __builtin_amdgcn_update_dpp(v, v, K * 0x55, 0xF, 0xF, false); }
 
 // Waits until state k of the trajectory in X has arrived (see above).  false: gave up.
+// LONG_NAP: sleep ≈ 1000 ticks between polls instead of ≈ 64 — every poll is an LDS instruction in the queue that the main
+// wavefront's stores (and the s_waitcnt lgkmcnt(0) of its every step) go through; only the last chunk's arrival is urgent.
+template <bool LONG_NAP>
 __device__ __forceinline__ bool state_arrived(const double* X, int k, int& budget) {
   const volatile unsigned long long* p = reinterpret_cast<const volatile unsigned long long*>(X + k * XR + 3);
   while (*p == THETA_PENDING) {
     if (--budget < 0) return false;
-    __builtin_amdgcn_s_sleep(1);
+    if (LONG_NAP) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(1);
   }
   asm volatile("" ::: "memory");  // the reads of the state lie behind the poll
   return true;
@@ -1038,18 +1055,42 @@ __device__ __forceinline__ void mark_pending(double* X, int N, int first_lane, i
 // Phase L of the two-wavefront kernel: one wavefront, lanes = 16 steps × 4; chunk c as soon as state min(16c + 16, N) is there.
 // Writes the records, the forward-pass rows {x, y, v, theta, u0, u1} of the old trajectory, J per step and the sum J → ctl[0].
 // false: a state did not arrive within the poll budget (ctl's abort word is set; the results are not to be used).
+// DIAG: dg[0] += ticks spent waiting for states, dg[1] += ticks of the chunks' work, dg[2] += ticks from the arrival of the last
+// state to the end (what the main wavefront waits for at the barrier), dg[3] += 1.
+template <bool DIAG>
 __device__ __forceinline__ bool linearize_quads(const KParams& kp, int N, int M, int lane, const double* samp, int S,
                                                 const SampleGrid& grid, const double* X, const double* U, double* rec,
-                                                const double* tab, const double* wts, double* fwd, double* Jt, double* ctl) {
+                                                const double* tab, const double* wts, double* fwd, double* Jt, double* ctl,
+                                                unsigned long long* dg) {
   const int sub = lane & 3;
   int budget = PAIR_SPIN;
   bool ok = true;
   const LdsSamples at{samp, grid.xf, grid.dxs};
-  for (int t0 = 0; t0 < N; t0 += 16) {
-    if (ok) ok = state_arrived(X, min(t0 + 16, N), budget);
+  unsigned long long tq = 0;
+  if (DIAG) tq = __builtin_readcyclecounter();
+  // Experiment switch of the stamped instantiation (flags bits 8-9; same results): 1 = poll for the states as usual but do the
+  // chunks' work only when the main wavefront's phase is over (an extra barrier there); 2 = no polling either.  Tells the cost
+  // of the polls and of the chunk work to the main wavefront's phase apart.
+  const int dbg = DIAG ? (int)((phase_args().flags >> 8) & 3) : 0;
+  if (dbg == 1 && ok) ok = state_arrived<true>(X, N, budget);
+  if (dbg) __syncthreads();
+  // Chunks of at most 16 steps, laid out from the END of the horizon: the last chunk holds the last PAIR_LAST steps — it can only
+  // start when the forward pass is over, and the chunk before it must be done by then, i.e. must have started one chunk's work
+  // (≈ 4 k ticks ≈ 10 forward steps) earlier; the first chunk takes what is left.
+  for (int t0 = 0, t1; t0 < N; t0 = t1) {
+    {
+      const int tail = N - t0;  // steps still to do
+      t1 = tail <= PAIR_LAST ? N : t0 + (tail - PAIR_LAST - 1) % 16 + 1;
+    }
+    if (ok && !dbg) ok = t1 < N ? state_arrived<true>(X, t1, budget) : state_arrived<false>(X, N, budget);
+    if (DIAG) {
+      const unsigned long long now_ = __builtin_readcyclecounter();
+      dg[0] += now_ - tq;
+      tq = now_;
+    }
     const int t = t0 + (lane >> 2);
-    const bool act = t < N;
-    const int tc = act ? t : N - 1;  // (lanes past the horizon repeat the last step and store nothing)
+    const bool act = t < t1;
+    const int tc = act ? t : t1 - 1;  // (lanes past the chunk repeat its last step and store nothing)
     const double* xr = X + tc * XR;
     const double* xn = X + (tc + 1) * XR;
     const double px = xr[0], py = xr[1], v = xr[2], th = xr[3], vn = xn[2], thn = xn[3];
@@ -1067,7 +1108,7 @@ __device__ __forceinline__ bool linearize_quads(const KParams& kp, int N, int M,
     // closest path sample: the window of closest_sample, its candidates dealt round-robin to the quad, then the lexicographic
     // minimum of (distance, index) over the quad — the strict-< first minimum of the ascending scan (I/Constraints.cpp:43-56)
     int lo, hi;
-    closest_window(S, grid, px, py, at, lo, hi);
+    closest_window<false>(S, grid, px, py, at, lo, hi);
     double md = __builtin_huge_val();
     int best = 0x7fffffff;
     int s = lo + sub;
@@ -1132,6 +1173,12 @@ __device__ __forceinline__ bool linearize_quads(const KParams& kp, int N, int M,
       r[10] = c.al; r[11] = c.be; r[12] = c.ga; r[13] = c.de;
       Jt[t] = J;
     }
+    if (DIAG) {
+      const unsigned long long now_ = stamp_after(J);
+      dg[1] += now_ - tq;
+      if (t1 >= N) dg[2] -= tq;
+      tq = now_;
+    }
   }
   // J = sum over the steps, in the order of the one-wavefront kernel: lanes = steps (t, t + 64, …), then wave_sum_uniform
   double part = 0.0;
@@ -1142,6 +1189,10 @@ __device__ __forceinline__ bool linearize_quads(const KParams& kp, int N, int M,
     if (!ok) reinterpret_cast<int*>(ctl + 1)[1] = 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the forward-pass rows have reached L2 before the barrier that follows
+  if (DIAG) {
+    dg[2] += __builtin_readcyclecounter();
+    dg[3] += 1;
+  }
   return ok;
 }
 
@@ -1211,17 +1262,24 @@ __global__ __launch_bounds__(2 * WAVE) void cilqr_solve_pair_kernel(SolveArgs a)
       }
       grid.dmax = wave_max_uniform(m);
     }
+    unsigned long long dg[4] = {0, 0, 0, 0};
     for (;;) {
-      linearize_quads(KParams(phase_params()), N, M, lane, samp, S, grid, Xa, Ua, rec, tab, wts, fwd, Jt, ctl);
+      linearize_quads<DIAG>(KParams(phase_params()), N, M, lane, samp, S, grid, Xa, Ua, rec, tab, wts, fwd, Jt, ctl, dg);
       __syncthreads();  // B2: the new trajectory is linearised
       __syncthreads();  // B1: main has decided (and, going on, has run R)
       if (*reinterpret_cast<volatile int*>(cmd) != CMD_GO) break;
+    }
+    if (DIAG && lane == 0 && a.diag) {  // slots 8..11: the aux wavefront's own account (cilqr_set_diag_buffer)
+      unsigned long long* o = a.diag + (size_t)b * DIAG_SLOTS + 8;
+      o[0] = dg[0]; o[1] = dg[1]; o[2] = dg[2]; o[3] = dg[3];
     }
     return;
   }
 
   // ---- the main wavefront ------------------------------------------------------------------------------------------------
   bool handover = !rollout_fast<true>(kp, N, a.x0 + (size_t)b * 4, Ua, Xa);  // nominal rollout, I/iLQR.cpp:51-62
+  const int dbg = DIAG ? (int)((a.flags >> 8) & 3) : 0;  // (linearize_quads)
+  if (dbg) __syncthreads();
   __syncthreads();  // B2
   CILQR_STAMP(c_pro)
   double J_old = DBL_MAX, lamb = 1.0, J_new = 0.0;
@@ -1254,6 +1312,7 @@ __global__ __launch_bounds__(2 * WAVE) void cilqr_solve_pair_kernel(SolveArgs a)
     if (DIAG) ++n_R;
     const bool f_ok = forward_smem<true>(KParams(phase_params()), N, Xa, fwd, Xa, Ua);
     CILQR_STAMP(c_F)
+    if (dbg) __syncthreads();
     __syncthreads();  // B2
     CILQR_STAMP(c_L)
     if (!f_ok) { handover = true; break; }
@@ -1293,7 +1352,7 @@ __global__ __launch_bounds__(2 * WAVE) void cilqr_solve_pair_kernel(SolveArgs a)
     const unsigned long long now_ = __builtin_readcyclecounter();
     unsigned long long* o = a.diag + (size_t)b * DIAG_SLOTS;
     o[0] = c_pro; o[1] = c_L; o[2] = c_R; o[3] = c_F; o[4] = now_ - tk; o[5] = n_L; o[6] = n_R; o[7] = now_ - tk0;
-    for (int q = 0; q < 8; ++q) o[8 + q] = sub[q];
+    for (int q = 4; q < 8; ++q) o[8 + q] = sub[q];  // (slots 8..11: written by the aux wavefront)
   }
 #undef CILQR_STAMP
 }
