@@ -472,6 +472,41 @@ def test_pair_kernel_weights_warm_starts_and_hand_over(cilqr, oracle, monkeypatc
     _compare({k: v[keep] for k, v in got.items()}, _oracle_batch(oracle, N, sub), TIGHT, "two wavefronts, weights and warm starts")
 
 
+@pytest.mark.parametrize("G,B,N,M", [(8, 520, 80, 16), (1, 300, 30, 2), (4, 333, 50, 4), (16, 90, 50, 5), (32, 40, 64, 3), (2, 257, 20, 0)])
+def test_lane_sharing_changes_no_bit(cilqr, oracle, monkeypatch, G, B, N, M):
+    """Grouped family, phase L: the lanes of a wavefront's finished solves take steps of the unfinished ones (floor(64 / k) lanes
+    per solve with k solves active).  The result of a solve must not depend on it: bit-identical U, X, J, iterations and exits
+    with the sharing switched off (CILQR_NO_LANE_SHARING), for every lane grouping, ragged batches (the last wavefront partly
+    empty), warm-started controls and per-obstacle weights; and equal to the oracle."""
+    from cilqr_amd import scenes
+    monkeypatch.setenv("CILQR_FORCE_G", str(G))
+    p = cilqr.default_params(N)
+    sc = scenes.make_static(B, N, M, p, 7300 + G)
+    rng = np.random.default_rng(7300 + G)
+    sc["U"] = sc["U"] + rng.normal(0.0, 0.2, sc["U"].shape)
+    if M:
+        sc["obs_weight"] = rng.uniform(0.3, 1.5, (B, M))
+    shared = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=max(M, 1), device=0)
+    monkeypatch.setenv("CILQR_NO_LANE_SHARING", "1")
+    plain = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=max(M, 1), device=0)
+    monkeypatch.delenv("CILQR_NO_LANE_SHARING")
+    try:
+        assert shared.solve_family(B, N, M) == G
+        got, ref = _gpu_batch(shared, sc), _gpu_batch(plain, sc)
+        flags = cilqr.FLAG_FAITHFUL_ITERS
+        gotf, reff = _gpu_batch(shared, sc, flags=flags), _gpu_batch(plain, sc, flags=flags)
+    finally:
+        shared.close()
+        plain.close()
+    for k in ("iters", "status", "U", "X", "J"):
+        assert np.array_equal(got[k], ref[k]), k
+        assert np.array_equal(gotf[k], reff[k]), "faithful " + k
+        assert np.array_equal(got[k], gotf[k]), "early exit against the reference loop: " + k
+    idx = np.arange(min(B, 96))
+    sub = {k: (v[idx] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in sc.items()}
+    _compare({k: v[idx] for k, v in got.items()}, _oracle_batch(oracle, N, sub), TIGHT, "lane sharing, G=%d" % G)
+
+
 def test_schedule_hint_changes_nothing_but_the_order(cilqr):
     """A batch beyond one solve per SIMD is dispatched longest-first by the pass counts of the previous call (same batch size,
     same stream).  Every call must return bit-identical results — the first (identity order), the second (hinted) and a third

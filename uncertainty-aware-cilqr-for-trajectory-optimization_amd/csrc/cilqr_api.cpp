@@ -213,6 +213,7 @@ int cilqr_create(const cilqr_params* p, int max_batch, int max_horizon, int max_
   h->hint_B = 0; h->hint_stream = nullptr;
   h->hint_off = getenv("CILQR_NO_SCHEDULE_HINT") != nullptr;
   h->pair_on = getenv("CILQR_PAIR_KERNEL") != nullptr;
+  h->steal_off = getenv("CILQR_NO_LANE_SHARING") != nullptr;
   if (err == hipSuccess) err = dmalloc(&h->d_pair, (size_t)2);
   if (err == hipSuccess) err = dmalloc(&h->d_triple, (size_t)3);
   if (err == hipSuccess) err = dmalloc(&h->d_gather, (size_t)3);
@@ -408,7 +409,7 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
   a.samp_off = nullptr; a.n_samples = 0; a.samp_w = 0.0;
   a.obs_tab = h->d_obs_tab;
   a.fwd = h->d_ws;  // (the grouped family's workspace: 42·N + 12 doubles per solve ≥ the 16·(N + 1) needed here; never both at once)
-  a.order = nullptr; a.hint_passes = nullptr; a.pair = 0;
+  a.order = nullptr; a.hint_passes = nullptr; a.pair = 0; a.steal = h->steal_off ? 0 : 1;
   a.redo = h->d_redo;
   a.diag = h->diag;
   a.passes = h->passes;
@@ -465,7 +466,7 @@ int cilqr_solve_batch_sampled_device(cilqr_handle* h, void* stream, int B, int N
   a.samp_off = sample_offset; a.n_samples = n_samples; a.samp_w = sample_weight;
   a.obs_tab = h->d_obs_tab;  // n_obs·N·8 doubles per solve ≤ the n_obs·n_samples·N·6 reserved for the materialised form
   a.fwd = h->d_ws;
-  a.pair = 0;
+  a.pair = 0; a.steal = 0;
   a.redo = h->d_redo;
   a.diag = h->diag;
   a.passes = h->passes;

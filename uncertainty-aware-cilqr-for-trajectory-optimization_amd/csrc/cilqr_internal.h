@@ -69,6 +69,8 @@ struct SolveArgs {
   // 1: the batch has at most one solve per SIMD — the launcher may give every solve a second wavefront (cilqr_solve.hip,
   // cilqr_solve_pair_kernel: the next linearisation runs behind the forward pass instead of after it)
   int32_t pair;
+  // grouped family: 1 = in phase L the lanes of a wavefront's finished solves take steps of the unfinished ones (cilqr_solve_groups.hip)
+  int32_t steal;
   KParams kp;
   UncArgs unc;
 };

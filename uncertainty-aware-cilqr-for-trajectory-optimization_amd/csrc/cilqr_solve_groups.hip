@@ -23,6 +23,16 @@
 // where the wavefront is whole and run with the hardware's own EXEC — nothing forces EXEC or touches registers of lanes the
 // compiler believes inactive.
 //
+// Lane sharing in phase L (round 3).  The solves of a wavefront differ widely in length (config 5: 35 % run all 20 iterations,
+// the rest end anywhere from the 2nd on), and a wavefront stays in its loop until its last solve has finished: measured with
+// tools/group_idle.py, its lane groups are busy 62 % of the loop at S = 8 (config 5), 41 % at S = 16, 37 % at S = 64.  R and F
+// are sequential per solve and cost the same however many solves are left — but phase L, the largest phase, is a set of
+// independent (solve, step) items, so the lanes of finished solves take steps of the unfinished ones: with k solves active every
+// one of them gets floor(64 / k) lanes instead of G.  What a helper lane needs of a solve (polynomial, sample grid, held-obstacle
+// mask, buffer in use) lies in a small per-solve block in LDS; the stage cost of a step goes through LDS to the solve's OWN lanes,
+// which add the steps up in the order they always did — the result of a solve does not depend on who shares its wavefront
+// (permutation tests), and is bit-identical to the unshared mapping (CILQR_NO_LANE_SHARING at cilqr_create switches it off).
+//
 // Arithmetic is shared with the LDS family (cilqr_device.hpp): same per-step functions, same samples, same fast/GENERAL
 // split with the redo hand-over.  Path samples are recomputed where needed (12 instructions) instead of stored.
 #include "cilqr_device.hpp"
@@ -61,6 +71,9 @@ __device__ __forceinline__ void mem_sync() {
 
 extern __shared__ __attribute__((aligned(16))) double cilqr_groups_lds[];
 constexpr int F_ROWS = XR + 2 + KR;  // forward pass: 6 state + 2 control + 10 gain rows per step
+// Per-solve block in LDS (phase L's lane sharing): {poly[6], xf, dxs, inv_dxs, dmax, windowed, held mask, map pose[4], xc | uc}
+constexpr int PAR = 18;
+constexpr int P_XF = 6, P_DXS = 7, P_INV = 8, P_DMAX = 9, P_WIN = 10, P_HELD = 11, P_POSE = 12, P_BUF = 16;
 
 // n_doubles (even) contiguous doubles from src (global, wave-uniform) to dst (LDS, wave-uniform) by the asynchronous
 // direct-to-LDS load: 16 bytes per lane and instruction, no data registers.  Called only where the wavefront is whole (see the
@@ -70,7 +83,10 @@ __device__ __forceinline__ void stage_copy(const double* src, double* dst, int n
   const unsigned lds0 = __builtin_amdgcn_groupstaticsize() + (unsigned)((dst - cilqr_groups_lds) * sizeof(double));
   const unsigned lane16 = threadIdx.x * 16u;
   for (int off = 0; off < bytes; off += WAVE * 16) {
-    const unsigned long long piece = reinterpret_cast<unsigned long long>(src) + (unsigned long long)off;
+    // (wave-uniform by construction; said so to the compiler, which otherwise may hold it in vector registers — the "s" operand below)
+    const unsigned long long piece0 = reinterpret_cast<unsigned long long>(src) + (unsigned long long)off;
+    const unsigned long long piece = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(piece0 >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((int)piece0);
     const unsigned lds_byte = lds0 + (unsigned)off;
     if ((int)lane16 < bytes - off) {
       unsigned m0_save;
@@ -92,9 +108,12 @@ __device__ __forceinline__ void stage_wait() { asm volatile("s_waitcnt vmcnt(0)"
 // chunk_r: steps per L→R hand-over chunk (a multiple of G); chunk_f: steps per forward-pass staging chunk (two buffers).
 // UNC: an uncertainty map is set — a separate instantiation, so that without a map none of its code is in the kernel.
 template <int G, bool UNC>
-__global__ __launch_bounds__(WAVE) void cilqr_solve_groups_fast(SolveArgs a, double* ws_base, int chunk_r, int chunk_f) {
+__global__ __launch_bounds__(WAVE) void cilqr_solve_groups_fast(SolveArgs a, double* ws_base, int chunk_r, int chunk_f, int lds_main) {
   double* lds = cilqr_groups_lds;
   constexpr int S = WAVE / G;
+  double* const Jt = lds + lds_main;                  // [chunk_r][S]: stage cost of each step of the chunk in hand
+  double* const par = Jt + (size_t)chunk_r * S;       // [S][PAR]: the per-solve blocks
+  int* const alist = reinterpret_cast<int*>(par + (size_t)S * PAR);  // [S]: the solves phase L works on in this iteration
   const int lane = threadIdx.x, grp = lane / G, g = lane % G;
   const int b = blockIdx.x * S + grp;
   const bool live = b < a.B;  // lanes past the batch stay in the wavefront, switched off (whole groups)
@@ -117,7 +136,6 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_fast(SolveArgs a, dou
   SampleGrid grid;
   make_sample_grid(grid, 0.0, 1.0, NS);
   unsigned long long held = 0;
-  const double* wts = nullptr;
   bool handover = false;
   auto sample_at = [&](int s, double& x, double& y) { sample_xy(grid, pc, s, x, y); };
   auto store_state = [&](int base, int t, const State& s) {
@@ -148,7 +166,6 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_fast(SolveArgs a, dou
       UF(L.ua(), t, 0) = Ug[2 * t];
       UF(L.ua(), t, 1) = Ug[2 * t + 1];
     }
-    wts = a.obs_weight ? a.obs_weight + (size_t)b * M : nullptr;
     // Obstacle table, I/Obstacle.cpp:41-62.  An obstacle whose pose and dimensions are the same in every column (how the
     // reference node feeds static obstacles: one pose replicated over the horizon, I/ilqr_uncertainty_node.cpp:175-185) gets a
     // bit in `held`: phase L then reads its step-0 row for every step — the same values, but one cache-resident line per
@@ -178,6 +195,15 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_fast(SolveArgs a, dou
   }
   UncPose upose{0, 0, 1, 0};
   if (UNC && live) upose = unc_pose(a.unc, b);
+  if (live && g == 0) {  // the per-solve block of phase L's lane sharing
+    double* q = par + (size_t)grp * PAR;
+#pragma unroll
+    for (int j = 0; j < CILQR_POLY_COEFFS; ++j) q[j] = pc[j];
+    q[P_XF] = grid.xf; q[P_DXS] = grid.dxs; q[P_INV] = grid.inv_dxs; q[P_DMAX] = grid.dmax; q[P_WIN] = grid.windowed ? 1.0 : 0.0;
+    reinterpret_cast<unsigned long long*>(q)[P_HELD] = held;
+    q[P_POSE] = upose.px; q[P_POSE + 1] = upose.py; q[P_POSE + 2] = upose.cp; q[P_POSE + 3] = upose.sp;
+    reinterpret_cast<int*>(q + P_BUF)[0] = L.xa(); reinterpret_cast<int*>(q + P_BUF)[1] = L.ua();
+  }
   mem_sync();
   if (live) {  // nominal rollout, I/iLQR.cpp:51-62
     const double* x0 = a.x0 + (size_t)b * 4;
@@ -212,6 +238,26 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_fast(SolveArgs a, dou
   for (int it = 0; it < max_it; ++it) {
     if (__builtin_amdgcn_ballot_w64(active) == 0) break;
     if (active) ++iters;
+    // ---- who linearises what in this iteration: the k active solves, floor(64 / k) lanes each (lanes j, j + k, … work for the
+    // j-th active solve, so that neighbouring lanes touch neighbouring columns of a workspace row).  Without lane sharing: every
+    // solve of the wavefront is listed and keeps its own G lanes; the lanes of a finished one find it inactive and idle.
+    int k_act, lanes_per, my_slot = -1, my_sub = 0;
+    {
+      const unsigned long long lead = __builtin_amdgcn_ballot_w64(active && g == 0);
+      if (a.steal) {
+        k_act = __builtin_popcountll(lead);
+        if (active && g == 0) alist[__builtin_popcountll(lead & ((1ull << lane) - 1ull))] = grp;
+      } else {
+        k_act = S;
+        if (g == 0) alist[grp] = active ? grp : -1;
+      }
+      __syncthreads();  // (one wavefront per workgroup: orders the LDS traffic, waits for nobody)
+      lanes_per = WAVE / (k_act > 0 ? k_act : 1);
+      if (k_act > 0 && lane < k_act * lanes_per) {
+        my_slot = alist[lane % k_act];
+        my_sub = lane / k_act;
+      }
+    }
     // ---- phases L and R, fused: chunks of steps from the end of the horizon; the records of a chunk go L → LDS → R
     double Jpart = 0.0;
     bool r_ok = true;
@@ -220,13 +266,27 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_fast(SolveArgs a, dou
     for (int hi = N - 1; hi >= 0;) {
       const int lo = hi - chunk_r + 1 < 0 ? 0 : hi - chunk_r + 1;
       unsigned long long t0 = a.diag ? __builtin_readcyclecounter() : 0;
-      if (active) {
-        // this lane's steps lo + g, lo + g + G, … ≤ hi: the ten operands of the next one are requested while the current computes
+      if (my_slot >= 0) {
+        // this lane's steps lo + my_sub, lo + my_sub + lanes_per, … ≤ hi of solve my_slot: the ten operands of the next one are
+        // requested while the current computes
+        const double* q = par + (size_t)my_slot * PAR;
+        double pcs[CILQR_POLY_COEFFS];
+#pragma unroll
+        for (int j = 0; j < CILQR_POLY_COEFFS; ++j) pcs[j] = q[j];
+        SampleGrid gs;
+        gs.xf = q[P_XF]; gs.dxs = q[P_DXS]; gs.inv_dxs = q[P_INV]; gs.dmax = q[P_DMAX]; gs.windowed = q[P_WIN] != 0.0;
+        const unsigned long long held_s = reinterpret_cast<const unsigned long long*>(q)[P_HELD];
+        const int xcs = reinterpret_cast<const int*>(q + P_BUF)[0], ucs = reinterpret_cast<const int*>(q + P_BUF)[1];
+        const int bs = blockIdx.x * S + my_slot;
+        const double* wss = wave_ws + my_slot;  // column my_slot of this wavefront's workspace block
+        const double* tabs = a.obs_tab + (size_t)blockIdx.x * ((size_t)M * N * TABF) * S + (size_t)my_slot * TABF;
+        const double* wtss = a.obs_weight ? a.obs_weight + (size_t)bs * M : nullptr;
+        auto sample_s = [&](int s_, double& x, double& y) { sample_xy(gs, pcs, s_, x, y); };
         struct LIn { double px, py, v, ct, st, u0, u1, vn, cn, sn; };
         auto load_in = [&](LIn& o, int t) {
-          const double* xr = &XF(xc, t, 0);
-          const double* xq = &XF(xc, t + 1, 0);
-          const double* ur = &UF(uc, t, 0);
+          const double* xr = wss + (size_t)(xcs + t * XR) * S;
+          const double* xq = wss + (size_t)(xcs + (t + 1) * XR) * S;
+          const double* ur = wss + (size_t)(ucs + t * 2) * S;
           o.px = xr[0]; o.py = xr[S]; o.v = xr[2 * S]; o.ct = xr[4 * S]; o.st = xr[5 * S];
           o.u0 = ur[0]; o.u1 = ur[S];
           o.vn = xq[2 * S]; o.cn = xq[4 * S]; o.sn = xq[5 * S];
@@ -234,35 +294,37 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_fast(SolveArgs a, dou
         const KParams kpl = phase_params();  // this phase's own read of the parameter block (cilqr_device.hpp)
         const UncArgs* unc = UNC ? &aq->unc : nullptr;
         LIn cur, nxt;
-        if (lo + g <= hi) load_in(cur, lo + g);
-        for (int t = lo + g; t <= hi; t += G) {
-          if (t + G <= hi) load_in(nxt, t + G);
-          const int cs = closest_sample(NS, grid, cur.px, cur.py, sample_at);
+        if (lo + my_sub <= hi) load_in(cur, lo + my_sub);
+        for (int t = lo + my_sub; t <= hi; t += lanes_per) {
+          if (t + lanes_per <= hi) load_in(nxt, t + lanes_per);
+          const int cs = closest_sample(NS, gs, cur.px, cur.py, sample_s);
           double cx, cy;
-          sample_xy(grid, pc, cs, cx, cy);
+          sample_xy(gs, pcs, cs, cx, cy);
           // one 48-byte entry = three 16-byte loads from one address; a held obstacle reads its step-0 entry
           auto obs = [&](int m, ObsEntry& e, double& w) {
-            const int row = (m < 64 && ((held >> m) & 1)) ? 0 : t;
-            const double2* p = reinterpret_cast<const double2*>(tab + ((size_t)m * N + row) * S * TABF);
+            const int row = (m < 64 && ((held_s >> m) & 1)) ? 0 : t;
+            const double2* p = reinterpret_cast<const double2*>(tabs + ((size_t)m * N + row) * S * TABF);
             const double2 q0 = p[0], q1 = p[1], q2 = p[2];
             e.ox = q0.x; e.oy = q0.y; e.co = q1.x; e.so = q1.y; e.ia2 = q2.x; e.ib2 = q2.y;
-            w = wts ? wts[m] : kpl.w_obstacle;
+            w = wtss ? wtss[m] : kpl.w_obstacle;
             return true;
           };
           Rec c;
-          Jpart += lin_step(kpl, cur.px, cur.py, cur.v, cur.ct, cur.st, cur.u0, cur.u1, cur.vn, cur.cn, cur.sn, cx, cy, M, obs, c);
-          double* r = lds + (size_t)(t - lo) * REC * S + grp;  // the record of step t, column grp of the chunk in LDS
+          Jt[(size_t)(t - lo) * S + my_slot] =
+              lin_step(kpl, cur.px, cur.py, cur.v, cur.ct, cur.st, cur.u0, cur.u1, cur.vn, cur.cn, cur.sn, cx, cy, M, obs, c);
+          double* r = lds + (size_t)(t - lo) * REC * S + my_slot;  // the record of step t, column my_slot of the chunk in LDS
           r[0] = c.lx0; r[S] = c.lx1; r[2 * S] = c.lx2; r[3 * S] = c.l00; r[4 * S] = c.l01; r[5 * S] = c.l11;
           r[6 * S] = c.lu0; r[7 * S] = c.lu1; r[8 * S] = c.luu0; r[9 * S] = c.luu1;
           r[10 * S] = c.al; r[11 * S] = c.be; r[12 * S] = c.ga; r[13 * S] = c.de; r[14 * S] = c.p; r[15 * S] = c.q;
           cur = nxt;
         }
         if (unc) {  // the map's term joins l_x, l_xx after the obstacles' (I/Constraints.cpp:188-201), in a loop of its own
-          for (int t = lo + g; t <= hi; t += G) {
-            const double* xr = &XF(xc, t, 0);
-            double* r = lds + (size_t)(t - lo) * REC * S + grp;
+          const UncPose ups{q[P_POSE], q[P_POSE + 1], q[P_POSE + 2], q[P_POSE + 3]};
+          for (int t = lo + my_sub; t <= hi; t += lanes_per) {
+            const double* xr = wss + (size_t)(xcs + t * XR) * S;
+            double* r = lds + (size_t)(t - lo) * REC * S + my_slot;
             double lx0 = r[0], lx1 = r[S], h00 = r[3 * S], h01 = r[4 * S], h11 = r[5 * S];
-            unc_cost_add(*unc, upose, b, xr[0], xr[S], xr[4 * S], xr[5 * S], lx0, lx1, h00, h01, h11);
+            unc_cost_add(*unc, ups, bs, xr[0], xr[S], xr[4 * S], xr[5 * S], lx0, lx1, h00, h01, h11);
             r[0] = lx0; r[S] = lx1; r[3 * S] = h00; r[4 * S] = h01; r[5 * S] = h11;
           }
         }
@@ -270,6 +332,8 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_fast(SolveArgs a, dou
       __syncthreads();  // the chunk's records are in LDS (one wavefront per workgroup: this orders LDS traffic, it waits for nobody)
       if (a.diag && active) { const unsigned long long t1 = __builtin_readcyclecounter(); tL += t1 - t0; t0 = t1; }
       if (active) {
+        // the stage costs of this chunk's steps, summed by the solve's own lanes in the order of the unshared mapping
+        for (int t = lo + g; t <= hi; t += G) Jpart += Jt[(size_t)(t - lo) * S + grp];
         auto lds_rec = [&](Rec& o, int t_rel) {
           const double* r = lds + (size_t)t_rel * REC * S + grp;
           o.lx0 = r[0]; o.lx1 = r[S]; o.lx2 = r[2 * S]; o.l00 = r[3 * S]; o.l01 = r[4 * S]; o.l11 = r[5 * S];
@@ -436,6 +500,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_fast(SolveArgs a, dou
       if (accept) {
         int sx = xc; xc = xn; xn = sx;
         int su = uc; uc = un; un = su;
+        if (g == 0) { int* qb = reinterpret_cast<int*>(par + (size_t)grp * PAR + P_BUF); qb[0] = xc; qb[1] = uc; }
         j_valid = false;
         lamb = lamb / kp.lamb_factor;
         if (fabs(J_new - J_old) < kp.tolerance) { status = CILQR_EXIT_TOLERANCE; active = false; }
@@ -682,7 +747,8 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_general(SolveArgs a, 
 #undef KF
 }
 
-constexpr int LDS_BUDGET = 36 * 1024;  // per wavefront: four wavefronts per CU, one per SIMD, within the CU's 160 KiB
+constexpr int LDS_BUDGET = 34 * 1024;  // chunk area per wavefront: four wavefronts per CU, one per SIMD, within the CU's 160 KiB
+                                       // together with the ≤ 6 KiB of stage costs and per-solve blocks behind it
 
 template <int G>
 void launch_g(const SolveArgs& a, double* ws, hipStream_t stream) {
@@ -698,11 +764,14 @@ void launch_g(const SolveArgs& a, double* ws, hipStream_t stream) {
   if (chunk_f < 1) chunk_f = 1;
   if (chunk_f > a.N) chunk_f = a.N;
   const size_t lds_r = (size_t)chunk_r * REC * S * sizeof(double), lds_f = (size_t)2 * chunk_f * F_ROWS * S * sizeof(double);
-  const size_t lds = lds_r > lds_f ? lds_r : lds_f;
+  const size_t lds_main = lds_r > lds_f ? lds_r : lds_f;
+  // behind the chunk area: stage costs of the chunk in hand, the per-solve blocks, the list of active solves (phase L's lane sharing)
+  const size_t lds = lds_main + ((size_t)chunk_r * S + (size_t)S * PAR + (size_t)(S + 1) / 2) * sizeof(double);
+  const int lds_main_doubles = (int)(lds_main / sizeof(double));
   const WsLayout L{a.N, a.M};
   double* rec_ws = ws + ((size_t)a.B + WAVE - 1) / WAVE * WAVE * (size_t)L.rows();  // behind the trajectory/gain blocks
-  if (a.unc.layer) hipLaunchKernelGGL((cilqr_solve_groups_fast<G, true>), dim3(blocks), dim3(WAVE), lds, stream, a, ws, chunk_r, chunk_f);
-  else hipLaunchKernelGGL((cilqr_solve_groups_fast<G, false>), dim3(blocks), dim3(WAVE), lds, stream, a, ws, chunk_r, chunk_f);
+  if (a.unc.layer) hipLaunchKernelGGL((cilqr_solve_groups_fast<G, true>), dim3(blocks), dim3(WAVE), lds, stream, a, ws, chunk_r, chunk_f, lds_main_doubles);
+  else hipLaunchKernelGGL((cilqr_solve_groups_fast<G, false>), dim3(blocks), dim3(WAVE), lds, stream, a, ws, chunk_r, chunk_f, lds_main_doubles);
   hipLaunchKernelGGL((cilqr_solve_groups_general<G>), dim3(blocks), dim3(WAVE), 0, stream, a, ws, rec_ws);
 }
 
