@@ -567,6 +567,11 @@ def main():
                          "sampled obstacles; c5: B=8192 per GPU N=80 M=16; warp: config 4, 1024x1024 costmap frames")
     ap.add_argument("--frames", type=int, default=1, help="warp only: K frames per launch (cilqr_warp_costmap_batch_device)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ticks", action="store_true",
+                    help="solver workloads: every step solves the NEXT tick of a closed-loop planner sequence (ego moved one step along the "
+                         "accepted plan, warm-started controls, re-fitted local plan, obstacles moved on, fresh pose noise) instead of the "
+                         "same batch again; the sequence is generated before the timed region and lies in HBM.  Default for --workload c3.")
+    ap.add_argument("--repeat-batch", action="store_true", help="c3: the old behaviour, one batch solved again and again")
     ap.add_argument("--materialised", action="store_true",
                     help="c3 only: pass the 256 sampled obstacles as 256 ordinary obstacle tables (cilqr_solve_batch_device) instead "
                          "of the compact nominal + offsets form (cilqr_solve_batch_sampled_device)")
@@ -637,6 +642,7 @@ def main():
         pose, dim = dv(sc["obs_pose"]), dv(sc["obs_dim"])
         wts = dv(sc["obs_weight"]) if sc["obs_weight"] is not None else None
     U = U0.clone()
+    use_ticks = (args.ticks or args.workload == "c3") and not args.repeat_batch and not args.materialised
     X = torch.zeros(B, 4 * (N + 1), dtype=torch.float64, device=dev)
     J = torch.zeros(B, dtype=torch.float64, device=dev)
     iters = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -648,7 +654,12 @@ def main():
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
+    tick_in = []  # --ticks: the device-resident inputs of tick 0, 1, … (warm-up ticks first)
+    last_host = None  # … and the host arrays of the last one (the oracle's inputs for the parity figure)
+    cur = {"x0": x0, "U0": U0, "poly": poly, "xpl": xpl, "pose": pose, "dim": dim, "offs": offs if sampled else None}
+
     def launch(slv):
+        x0, poly, xpl, pose, dim, offs = cur["x0"], cur["poly"], cur["xpl"], cur["pose"], cur["dim"], cur["offs"]
         if sampled:
             slv.solve_batch_sampled_device(stream, B, N, n_dyn, n_smp, x0.data_ptr(), U.data_ptr(), poly.data_ptr(), xpl.data_ptr(),
                                            pose.data_ptr(), dim.data_ptr(), offs.data_ptr(), sc["sample_weight"], X.data_ptr(),
@@ -658,8 +669,13 @@ def main():
                                    dim.data_ptr(), wts.data_ptr() if wts is not None else 0, X.data_ptr(), J.data_ptr(),
                                    iters.data_ptr(), status.data_ptr())
 
+    tick_no = [0]
+
     def step(k=None):
-        U.copy_(U0)
+        if use_ticks:  # the next tick of the sequence: another batch every step
+            cur.update(tick_in[tick_no[0]])
+            tick_no[0] += 1
+        U.copy_(cur["U0"])
         if k is not None:
             ev0[k].record()
         launch(solver)
@@ -667,6 +683,28 @@ def main():
             ev1[k].record()
         # local argmin + ONE ncclAllGather of 24 bytes per rank + the pick, all enqueued by cilqr_argmin_global_device
         return select_min_cost_device(solver, stream, B, J.data_ptr(), rank * B, pair)
+
+    if use_ticks:
+        # Closed-loop generation, untimed: tick t + 1 comes from the results of tick t (scenes.TickSequence), so the whole sequence
+        # of warmup + steps ticks is solved once here and its inputs are kept on the device for the timed replay.
+        ts = scenes.TickSequence("c3" if sampled else "static", B, p, N=N, M=M,
+                                 seed={"c2": scenes.SEED0 + 2 + 1000 * rank, "c5": scenes.SEED0 + 5 + 1000 * rank}.get(args.workload))
+        for t in range(args.warmup + args.steps):
+            i = ts.inputs()
+            d = {"x0": dv(i["x0"]), "U0": dv(i["U"]), "poly": dv(i["poly"]), "xpl": dv(i["xplan_fl"])}
+            if sampled:
+                d.update(pose=dv(i["nom_pose"]), dim=dv(i["nom_dim"]), offs=dv(i["offsets"]))
+            else:
+                d.update(pose=dv(i["obs_pose"]), dim=dv(i["obs_dim"]), offs=None)
+            tick_in.append(d)
+            cur.update(d)
+            U.copy_(d["U0"])
+            launch(solver)
+            torch.cuda.synchronize()
+            last_host = i
+            if t + 1 < args.warmup + args.steps:
+                ts.advance(X.cpu().numpy(), U.cpu().numpy())
+        del ts
 
     for _ in range(args.warmup):
         step()
@@ -715,7 +753,8 @@ def main():
             "metric": "CILQR solves/sec (N=%d, batch B)" % N, "value": value, "unit": "solves/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": wl + ", inputs resident in HBM, + min-cost selection",
+            "config": {"workload": wl + (", a closed-loop sequence of planner ticks (another batch every step; scenes.TickSequence)" if use_ticks else "")
+                                   + ", inputs resident in HBM, + min-cost selection",
                        "batch_per_gpu": B, "horizon": N, "obstacles": M, "mean_reference_iterations": mean_iters,
                        "parallelism": "scene-sharded x%d, one ncclAllGather of 24 B per rank behind cilqr_argmin_global_device" % world},
             "roofline": {"bound": "hbm", "kernel": "cilqr_solve_kernel" if lanes == 64 else "cilqr_solve_groups_fast<%d>" % lanes,
@@ -737,24 +776,44 @@ def main():
         wave_family = lanes == 64
         if wave_family and B > 1024 and world == 1:
             # Batches beyond one solve per SIMD are dispatched longest-first by the pass counts of the PREVIOUS call (DESIGN.md
-            # §4.1d).  The timed steps repeat one batch, the best case for that hint; beside it the same launch on a handle
-            # created with the hint switched off — what a first call, or a batch unrelated to the one before, gets.
+            # §4.1d).  That only pays when consecutive batches resemble each other solve by solve: beside the timed figure, the same
+            # launches on a handle created with the hint switched off.
             os.environ["CILQR_NO_SCHEDULE_HINT"] = "1"
             plain = cilqr_amd.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M, device=local_rank)
             del os.environ["CILQR_NO_SCHEDULE_HINT"]
-            c0 = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-            c1 = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-            for q in range(4):
-                U.copy_(U0)
+            reps = list(range(args.warmup, args.warmup + min(args.steps, 20))) if use_ticks else [None] * 4
+            c0 = [torch.cuda.Event(enable_timing=True) for _ in reps]
+            c1 = [torch.cuda.Event(enable_timing=True) for _ in reps]
+            for q, tk in enumerate(reps):
+                if tk is not None:
+                    cur.update(tick_in[tk])
+                U.copy_(cur["U0"])
                 c0[q].record()
                 launch(plain)
                 c1[q].record()
             torch.cuda.synchronize()
-            cold_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(c0[1:], c1[1:])]))
+            skip = 0 if use_ticks else 1
+            cold_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(c0[skip:], c1[skip:])]))
             plain.close()
             out["schedule_hint"] = {"active": True, "kernel_ms_without_hint": cold_ms, "solves_per_s_without_hint": B / (cold_ms * 1e-3),
-                                    "note": "value and roofline.kernel_ms are steady state on a repeated batch: the solves are dispatched "
-                                            "longest-first by the previous call's pass counts; without_hint = same launch, dispatch in index order"}
+                                    "note": ("the same ticks on a handle without the hint" if use_ticks else
+                                             "value and roofline.kernel_ms are steady state on a REPEATED batch, the hint's best case: the "
+                                             "solves are dispatched longest-first by the previous call's pass counts; without_hint = same "
+                                             "launch, dispatch in index order")}
+            if use_ticks:  # the repeated-batch figure, as a labelled note: the last tick solved five times over
+                r0 = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+                r1 = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+                for q in range(5):
+                    U.copy_(cur["U0"])
+                    r0[q].record()
+                    launch(solver)
+                    r1[q].record()
+                torch.cuda.synchronize()
+                rep_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(r0[2:], r1[2:])]))
+                out["schedule_hint"]["repeated_batch"] = {"kernel_ms": rep_ms, "solves_per_s": B / (rep_ms * 1e-3),
+                                                          "note": "NOT the value: one batch solved again and again, where the previous call's "
+                                                                  "pass counts predict this call's exactly (profiles/r03_schedule_hint_ticks.txt: "
+                                                                  "on tick sequences the hint changes nothing)"}
         cnt = RECORDED["workloads"].get(args.workload, {}).get("counters", {})
         if traffic_tag and "SQ_WAVE_CYCLES" in cnt:  # SQ counter pass of the same command, per launch: recorded, not live
             out["issue"] = {"recorded_from": RECORDED_FROM, "recorded_head": RECORDED.get("recorded_head"),
@@ -800,7 +859,13 @@ def main():
             po = O.default_params(N)
             ns = min(B, 1024 if M <= 16 else 128)  # bounded sample
             sl = lambda a: None if a is None else np.ascontiguousarray(a[:ns])  # noqa: E731
-            sample = [sl(sc[k]) for k in ("x0", "U", "poly", "xplan_fl", "obs_pose", "obs_dim", "obs_weight")]
+            src = sc
+            if use_ticks:  # the scenes of the LAST tick, whose results are the ones in U (materialised for the oracle where sampled)
+                src = dict(last_host)
+                if sampled:
+                    src["obs_pose"], src["obs_dim"], src["obs_weight"] = scenes.materialise_samples(
+                        last_host["nom_pose"][:ns], last_host["nom_dim"][:ns], last_host["offsets"][:ns], N)
+            sample = [sl(src[k]) for k in ("x0", "U", "poly", "xplan_fl", "obs_pose", "obs_dim", "obs_weight")]
             res = {}
 
             def cpu_call():
@@ -809,7 +874,7 @@ def main():
             want = res["want"]
             du = float(np.max(np.abs(U.cpu().numpy()[:ns] - want["U"])))
             out["cpu_baseline"] = {"value": rate, "unit": "solves/s", "cores": threads, "kind": "port",
-                                   "sample": "the first %d scenes of the same batch, OpenMP schedule(dynamic) over the batch; one untimed "
+                                   "sample": "the first %d scenes of the same batch (the last tick's), OpenMP schedule(dynamic) over the batch; one untimed "
                                              "call, then the median of 3 repetitions of %d calls (>= 2 s each)" % (ns, calls),
                                    "spread": spread, "per_core": rate / threads}
             out["max_abs_du_vs_oracle"] = du

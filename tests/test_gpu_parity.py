@@ -394,11 +394,12 @@ def test_automatic_family_choice_large_batch(cilqr, oracle):
 
 
 @pytest.mark.parametrize("B,N,M", [(2048, 50, 4), (8192, 50, 4), (2048, 80, 16)])
-def test_several_wavefronts_per_simd(cilqr, oracle, B, N, M):
-    """Batches of two to eight solves per SIMD still take the one-wavefront-per-solve family (the library's choice for
-    B ≤ 2 × SIMDs, and for N ≤ 64 up to 8 × SIMDs); N = 80 / M = 16 is the instantiation with the obstacle table in global
-    memory.  First, middle and last 64 solves against the oracle, the rest finite with a sane status."""
+def test_several_wavefronts_per_simd(cilqr, oracle, monkeypatch, B, N, M):
+    """Batches of two to eight solves per SIMD on the one-wavefront-per-solve family (forced here: the library keeps it for a
+    few solves per SIMD only while the solves are short, pick_group_lanes); N = 80 / M = 16 is the instantiation with the obstacle
+    table in global memory.  First, middle and last 64 solves against the oracle, the rest finite with a sane status."""
     from cilqr_amd import scenes
+    monkeypatch.setenv("CILQR_FORCE_G", "64")
     p = cilqr.default_params(N)
     sc = scenes.make_static(B, N, M, p, 402)
     s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M, device=0)
@@ -505,6 +506,30 @@ def test_lane_sharing_changes_no_bit(cilqr, oracle, monkeypatch, G, B, N, M):
     idx = np.arange(min(B, 96))
     sub = {k: (v[idx] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in sc.items()}
     _compare({k: v[idx] for k, v in got.items()}, _oracle_batch(oracle, N, sub), TIGHT, "lane sharing, G=%d" % G)
+
+
+def test_family_rule_on_measured_shapes(cilqr, oracle):
+    """The family rule (pick_group_lanes, drawn from profiles/r03_family_shapes.txt) at shapes on either side of its lines, and
+    one long-horizon batch end to end: N = 120, B = 4096 takes the wavefront family (5.9 ms against 6.7 ms grouped) and agrees with
+    the oracle on a sample."""
+    from cilqr_amd import scenes
+    N, M, B = 120, 4, 4096
+    p = cilqr.default_params(N)
+    s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=16, device=0)
+    try:
+        fam = s.solve_family
+        assert fam(1024, 50, 4) == 64 and fam(4096, 50, 4) == 64 and fam(8192, 50, 4) == 8 and fam(4096, 50, 8) == 16
+        assert fam(8192, 30, 2) == 64 and fam(16384, 30, 2) == 4 and fam(2048, 64, 4) == 64 and fam(4096, 64, 4) == 16
+        assert fam(2048, 80, 16) == 32 and fam(8192, 80, 16) == 8 and fam(65536, 80, 16) == 4 and fam(65536, 50, 4) == 2
+        assert fam(4096, 120, 4) == 64 and fam(16384, 160, 16) == 64 and fam(4096, 50, 256) == 64
+        sc = scenes.make_static(B, N, M, p, 7400)
+        got = _gpu_batch(s, sc)
+    finally:
+        s.close()
+    idx = np.concatenate([np.arange(32), np.arange(2000, 2032), np.arange(B - 32, B)])
+    sub = {k: (v[idx] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in sc.items()}
+    _compare({k: v[idx] for k, v in got.items()}, _oracle_batch(oracle, N, sub), TIGHT, "N = 120, B = 4096")
+    assert (got["iters"] >= 1).all()
 
 
 def test_schedule_hint_changes_nothing_but_the_order(cilqr):
@@ -1348,10 +1373,11 @@ def test_pass_count_buffer(cilqr, oracle):
     from cilqr_amd import scenes
     N, M = 50, 4
     p = cilqr.default_params(N)
-    for B in (96, 2048):  # wavefront family; grouped family
+    for B in (96, 8192):  # wavefront family; grouped family
         sc = scenes.make_static(B, N, M, p, 777)
         s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M, device=0)
         try:
+            assert (s.solve_family(B, N, M) == 64) == (B == 96)
             dev = torch.device("cuda", 0)
             t = {k: torch.from_numpy(np.ascontiguousarray(sc[k])).to(dev) for k in ("x0", "U", "poly", "xplan_fl", "obs_pose", "obs_dim")}
             X = torch.zeros(B, 4 * (N + 1), dtype=torch.float64, device=dev)

@@ -2,7 +2,8 @@
 """Kernel family by shape: wall time of cilqr_solve_batch_device for static scenes of several (N, M, B) in BOTH families — one
 wavefront per solve (CILQR_FORCE_G=64) and G lanes per solve (CILQR_FORCE_G = the automatic G for that batch) — beside what the
 library's own rule picks (cilqr_solve_family) and what that pick loses against the faster family.  Each figure is the best of
-four launches of one batch, i.e. with the schedule hint active from the second launch on.  Diagnostic tool; its table is
+four launches of one batch WITHOUT the schedule hint (CILQR_NO_SCHEDULE_HINT): on a planner's tick sequence the hint changes
+nothing (profiles/r03_schedule_hint_ticks.txt), so the dispatch-in-index-order figure is the one that decides.  Its table is
 profiles/rNN_family_shapes.txt and the rule in cilqr_api.cpp (pick_group_lanes) is drawn from it."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,6 +16,7 @@ _scene = {}
 
 
 def run(N, M, B, force):
+    os.environ["CILQR_NO_SCHEDULE_HINT"] = "1"
     if force: os.environ["CILQR_FORCE_G"] = str(force)
     else: os.environ.pop("CILQR_FORCE_G", None)
     p = cilqr_amd.default_params(N)
@@ -45,7 +47,8 @@ def run(N, M, B, force):
     s.close()
     return best, float(it.float().mean()), fam
 
-shapes = [(30, 2), (50, 0), (50, 4), (50, 8), (50, 12), (64, 4), (72, 4), (80, 4), (80, 8), (80, 16), (100, 4), (100, 16), (120, 4), (120, 16), (160, 4), (160, 16)]
+shapes = [(30, 2), (50, 0), (50, 4), (50, 8), (50, 12), (56, 4), (60, 4), (64, 0), (64, 4), (64, 8), (72, 4), (80, 4), (80, 8), (80, 16), (88, 4), (96, 4), (96, 16),
+          (100, 4), (100, 16), (120, 4), (120, 16), (160, 4), (160, 16)]
 if os.environ.get("SHAPES"):
     shapes = [tuple(int(v) for v in q.split("x")) for q in os.environ["SHAPES"].split(",")]
 worst = 0.0
@@ -54,6 +57,7 @@ for N, M in shapes:
         G = 32
         while G > 1 and G * B > 64 * 1024:
             G >>= 1
+        G = max(G, 4 if N > 64 else 2)  # (pick_group_lanes)
         _, _, fam = run(N, M, B, 0)
         w, iw, _ = run(N, M, B, 64)
         g, ig, _ = run(N, M, B, G)

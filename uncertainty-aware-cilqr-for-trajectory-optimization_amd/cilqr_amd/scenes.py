@@ -130,6 +130,19 @@ def make_c3(B=4096, params=None, local_plan=None, n_dyn=8, n_samples=32):
                 sample_weight=1.0 / n_samples, curve=curve)
 
 
+def materialise_samples(nom_pose, nom_dim, offsets, N):
+    """The M = n_dyn·n_samples ordinary obstacles a compact sampled scene stands for (what the reference's own Obstacle path is
+    given): (obs_pose (B, M, 4N), obs_dim (B, M, 2N), obs_weight (B, M))."""
+    B, n_dyn, n_samples = offsets.shape[:3]
+    pose = np.repeat(np.asarray(nom_pose).reshape(B, n_dyn, 1, N, 4), n_samples, axis=2).copy()
+    pose[..., 0] += offsets[..., 0][..., None]
+    pose[..., 1] += offsets[..., 1][..., None]
+    pose[..., 3] += offsets[..., 2][..., None]
+    dim = np.repeat(np.asarray(nom_dim).reshape(B, n_dyn, 1, N, 2), n_samples, axis=2)
+    M = n_dyn * n_samples
+    return pose.reshape(B, M, 4 * N), dim.reshape(B, M, 2 * N), np.full((B, M), 1.0 / n_samples)
+
+
 POSE_SIGMA = np.array([0.16, 0.16, 0.017])  # ilqr/launch/Experiment.launch:9-11 (sigma_x, sigma_y, sigma_theta)
 
 

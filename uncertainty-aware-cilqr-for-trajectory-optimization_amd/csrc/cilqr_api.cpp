@@ -67,24 +67,37 @@ hipError_t dmalloc(T** p, size_t n) {
 
 }  // namespace
 
-// Kernel family by batch shape (measured with tools/family_shapes.py, profiles/r03_family_shapes.txt): lanes per
-// solve, 64 = the one-wavefront-per-solve family (cilqr_solve.hip), less = the grouped family (cilqr_solve_groups.hip).  One
-// wavefront per solve, LDS-resident, up to two solves per SIMD (2048 on an MI355X) whatever the horizon, and up to eight when
-// the horizon fits one round of lanes (N ≤ 64): since the backward pass runs on the matrix cores, the forward pass takes its
-// operands through the scalar path and the workgroups are dispatched longest-first (schedule hint below), further wavefronts
-// on a SIMD cost that family less than the grouped family pays in global-memory traffic (config-2 scenes: B = 4096 0.53 ms
-// against 1.10 ms grouped, B = 8192 0.96-0.99 against 1.38-1.42; M = 0 and M = 8 at B = 8192 5-7 % the other way; N = 80 at
-// B = 4096 2.25 against 1.73).  Beyond that G lanes per solve, G the power of two nearest below 64·SIMDs/B (at most 32).
+// Kernel family by batch shape: lanes per solve, 64 = the one-wavefront-per-solve family (cilqr_solve.hip), less =
+// the grouped family (cilqr_solve_groups.hip).  Drawn from tools/family_shapes.py (profiles/r03_family_shapes.txt: both families
+// at N = 30 … 160, M = 0 … 16, B = 2048 … 16384, first calls, i.e. WITHOUT the schedule hint — on a planner's tick sequence
+// the hint changes nothing, profiles/r03_schedule_hint_ticks.txt) and tools/group_lanes_sweep.py.  Up to one solve per SIMD the
+// wavefront family always (its backward pass on the matrix cores and scalar-path forward pass give it the shorter serial chain);
+// beyond, it keeps batches of a few solves per SIMD while a solve is short — the shorter the horizon and the fewer the
+// obstacles, the longer — and the grouped family, whose phase L shares the lanes of finished solves since round 3, takes the
+// rest.  Very long horizons (N > 110: the records no longer fit the grouped family's LDS chunks well) stay on the wavefront
+// family at every size measured.
 static int pick_group_lanes(const cilqr_handle* h, int B, int N, int M) {
   const int f = h->force_g;
   if (f == 1 || f == 2 || f == 4 || f == 8 || f == 16 || f == 32 || f == 64) return f;
-  int G = 64;
-  if (B > 2 * h->simds && M <= 32 && !(N <= 64 && B <= 8 * h->simds)) {
-    // (with hundreds of obstacle entries per step the solve is a stream over its obstacle table: the wavefront-per-solve
-    // family reads it as whole 400-640 B rows per instruction and measures ≈2x faster there — BASELINE config 3)
-    G = 32;
-    while (G > 1 && (long)G * B > 64L * h->simds) G >>= 1;
-  }
+  // (with hundreds of obstacle entries per step the solve is a stream over its obstacle table: the wavefront-per-solve
+  // family reads it as whole 400-640 B rows per instruction and measures ≈2x faster there — BASELINE config 3)
+  if (M > 32 || N > 110) return 64;
+  // largest batch that stays on the wavefront family, in half solves per SIMD
+  int cap2;
+  if (N <= 32) cap2 = 16;
+  else if (N <= 56) cap2 = M <= 6 ? 8 : 4;
+  else if (N <= 64) cap2 = M <= 6 ? 4 : 3;
+  else if (N <= 92) cap2 = 3;
+  else cap2 = 8;
+  if (2L * B <= (long)cap2 * h->simds) return 64;
+  int G = 32;
+  while (G > 1 && (long)G * B > 64L * h->simds) G >>= 1;
+  // not below 2 lanes per solve (4 for horizons beyond one round of lanes): with the lanes of finished solves helping in phase L
+  // twice as many, smaller wavefronts — started as the first ones end — beat one wavefront per SIMD with 64 solves and 3-step
+  // hand-over chunks each (profiles/r03_group_lanes_sweep.txt: B = 65536, N = 50: G = 2 5.7 ms against 7.1 at G = 1; N = 80:
+  // G = 4 16.4-19.6 ms against 20.5-24.6)
+  const int g_min = N > 64 ? 4 : 2;
+  if (G < g_min) G = g_min;
   return G;
 }
 

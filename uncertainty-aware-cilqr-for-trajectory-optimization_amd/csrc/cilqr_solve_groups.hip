@@ -747,26 +747,28 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_general(SolveArgs a, 
 #undef KF
 }
 
-constexpr int LDS_BUDGET = 34 * 1024;  // chunk area per wavefront: four wavefronts per CU, one per SIMD, within the CU's 160 KiB
-                                       // together with the ≤ 6 KiB of stage costs and per-solve blocks behind it
+constexpr int LDS_BUDGET = 40 * 1024;  // per wavefront, everything: four wavefronts per CU, one per SIMD, within the CU's 160 KiB
 
 template <int G>
 void launch_g(const SolveArgs& a, double* ws, hipStream_t stream) {
   constexpr int S = WAVE / G;
   const int blocks = (a.B + S - 1) / S;
-  // L→R hand-over chunk: as many steps as fit, a whole number of rounds of the group's G lanes
-  int chunk_r = LDS_BUDGET / (REC * S * (int)sizeof(double));
+  // behind the chunk area: the per-solve blocks and the list of active solves (phase L's lane sharing), and one stage cost per
+  // step of the L→R chunk in hand
+  const int fixed = (S * PAR + (S + 1) / 2) * (int)sizeof(double);
+  // L→R hand-over chunk: as many steps as fit (16 record doubles + 1 stage cost per step and solve), a whole number of rounds of
+  // the group's G lanes
+  int chunk_r = (LDS_BUDGET - fixed) / ((REC + 1) * S * (int)sizeof(double));
   chunk_r = chunk_r / G * G;
   if (chunk_r < G) chunk_r = G;
   if (chunk_r > a.N) chunk_r = (a.N + G - 1) / G * G;
   // forward-pass staging chunk: two buffers
-  int chunk_f = LDS_BUDGET / (2 * F_ROWS * S * (int)sizeof(double));
+  int chunk_f = (LDS_BUDGET - fixed - chunk_r * S * (int)sizeof(double)) / (2 * F_ROWS * S * (int)sizeof(double));
   if (chunk_f < 1) chunk_f = 1;
   if (chunk_f > a.N) chunk_f = a.N;
   const size_t lds_r = (size_t)chunk_r * REC * S * sizeof(double), lds_f = (size_t)2 * chunk_f * F_ROWS * S * sizeof(double);
   const size_t lds_main = lds_r > lds_f ? lds_r : lds_f;
-  // behind the chunk area: stage costs of the chunk in hand, the per-solve blocks, the list of active solves (phase L's lane sharing)
-  const size_t lds = lds_main + ((size_t)chunk_r * S + (size_t)S * PAR + (size_t)(S + 1) / 2) * sizeof(double);
+  const size_t lds = lds_main + (size_t)chunk_r * S * sizeof(double) + (size_t)fixed;
   const int lds_main_doubles = (int)(lds_main / sizeof(double));
   const WsLayout L{a.N, a.M};
   double* rec_ws = ws + ((size_t)a.B + WAVE - 1) / WAVE * WAVE * (size_t)L.rows();  // behind the trajectory/gain blocks
