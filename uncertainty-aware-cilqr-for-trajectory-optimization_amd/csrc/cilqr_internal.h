@@ -125,7 +125,8 @@ struct WarpBatchArgs {
   float* dst;
   const float* bbox;          // may be null (one layer, shared by the frames)
   unsigned long long* n_oob;  // may be null
-  const double* poses;
+  const double* poses;        // null: ONE frame, its pose in pose0 (no table to upload)
+  double pose0[4];
   cilqr_map_geom sg, dg;
 };
 hipError_t launch_warp_batch(const WarpBatchArgs& a, int K, hipStream_t stream);

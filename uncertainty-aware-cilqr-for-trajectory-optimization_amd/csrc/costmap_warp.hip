@@ -33,6 +33,48 @@ __device__ __forceinline__ double neg_quotient_for_trunc(double t, double res, d
   return -(t / res);
 }
 
+// One destination cell the reference's way (getIndexFromPosition / checkIfPositionWithinMap on the rotated cell centre): the
+// source cell (si, sj), or false when the centre lies outside the source map.  tq receives (t_x, t_y) = the centre relative to the
+// source map's far corner, the quantity the neighbouring cells' estimates start from (cell_estimated).
+__device__ __forceinline__ bool cell_exact(const cilqr_map_geom& sg, double x_og, double y_og, double off_sx, double off_sy, double rres,
+                                           int& si, int& sj, double& t_x, double& t_y) {
+#pragma clang fp contract(off)
+  t_x = (x_og - off_sx) - sg.pos_x;
+  t_y = (y_og - off_sy) - sg.pos_y;
+  const double nx = neg_quotient_for_trunc(t_x, sg.res, rres);
+  const double ny = neg_quotient_for_trunc(t_y, sg.res, rres);
+  const double tx = -1.0 * ((x_og - sg.pos_x) - off_sx);
+  const double ty = -1.0 * ((y_og - sg.pos_y) - off_sy);
+  const bool fin = (nx > -2e9 && nx < 2e9 && ny > -2e9 && ny < 2e9);
+  si = fin ? (int)nx : -1;
+  sj = fin ? (int)ny : -1;
+  return (tx >= 0.0 && ty >= 0.0 && tx < sg.len_x && ty < sg.len_y) && (si >= 0 && sj >= 0 && si < sg.rows && sj < sg.cols);
+}
+
+// A NEIGHBOURING cell from an estimate of its (t_x, t_y): within a lane's run of cells the rotated centre advances by a constant
+// vector, so the neighbours' t are the first cell's plus multiples of that step — good to a few ulp of the coordinates, i.e.
+// ≈ 2^-50 of `mag` (the sum of every magnitude that enters a centre, in source cells).  The estimate decides a cell only when
+// its quotient is further than guard = mag·2^-40 from every integer — then the exact arithmetic above truncates to the same
+// index and lands on the same side of the map's edges (0 and rows are integers too); otherwise (a centre within 1e-12 of a
+// source-cell boundary: aligned grids, or once in ≈ 1e9 cells) false is returned and the caller evaluates the cell exactly.
+// ≈ 20 instructions against ≈ 48.  NaN and infinite poses fail the guard test and take the exact path.
+__device__ __forceinline__ bool cell_estimated(const cilqr_map_geom& sg, double t_x, double t_y, double nrres, double guard, bool& ok, int& si, int& sj) {
+#pragma clang fp contract(off)
+  const double qx = t_x * nrres, qy = t_y * nrres;  // nrres = -1/res
+  const double dx = __builtin_fabs(qx - __builtin_rint(qx)), dy = __builtin_fabs(qy - __builtin_rint(qy));
+  if (!(dx > guard && dy > guard)) return false;
+  ok = qx > 0.0 && qy > 0.0 && qx < (double)sg.rows && qy < (double)sg.cols;
+  si = ok ? (int)qx : -1;
+  sj = ok ? (int)qy : -1;
+  return true;
+}
+// mag·2^-40 (cell_estimated)
+__device__ __forceinline__ double estimate_guard(const cilqr_map_geom& sg, const cilqr_map_geom& dg, double vx, double vy, double rres) {
+  const double mag = (__builtin_fabs(sg.pos_x) + __builtin_fabs(sg.pos_y) + sg.len_x + sg.len_y + __builtin_fabs(dg.pos_x) + __builtin_fabs(dg.pos_y) +
+                      dg.len_x + dg.len_y + __builtin_fabs(vx) + __builtin_fabs(vy)) * rres;
+  return mag * 0x1p-40 + 0x1p-1000;
+}
+
 __global__ __launch_bounds__(NTHREADS) void warp_kernel(WarpArgs a, int tiles_i, int n_tiles) {
 #pragma clang fp contract(off)
   // XCD-aware remap: workgroup ids are dealt round-robin over the 8 XCDs (speed only, never correctness).
@@ -51,24 +93,28 @@ __global__ __launch_bounds__(NTHREADS) void warp_kernel(WarpArgs a, int tiles_i,
   const double Cx = (a.dg.pos_x + off_dx) + a.dg.res * (double)(-i);
   const double off_sx = 0.5 * a.sg.len_x, off_sy = 0.5 * a.sg.len_y;
   const double cxc = Cx * a.cos_t, cxs = Cx * a.sin_t;
-  const double rres = 1.0 / a.sg.res;
+  const double rres = 1.0 / a.sg.res, nrres = -rres;
+  const double guard = estimate_guard(a.sg, a.dg, a.vx, a.vy, rres);
+  // the wavefront's columns are four apart: the centre advances by (+4 res sin, -4 res cos) from one to the next
+  const double step_x = 4.0 * a.dg.res * a.sin_t, step_y = -4.0 * a.dg.res * a.cos_t;
+  double t0x = 0.0, t0y = 0.0;
   unsigned long long oob = 0;
 #pragma unroll
   for (int jj = 0; jj < TILE_J / 4; ++jj) {
     const int j = tj * TILE_J + wave + 4 * jj;
     if (j >= dcols || !in_i) break;
-    const double Cy = (a.dg.pos_y + off_dy) + a.dg.res * (double)(-j);
-    const double x_og = (cxc - Cy * a.sin_t) + a.vx;
-    const double y_og = (cxs + Cy * a.cos_t) + a.vy;
-    // getIndexFromPosition / checkIfPositionWithinMap
-    const double nx = neg_quotient_for_trunc((x_og - off_sx) - a.sg.pos_x, a.sg.res, rres);
-    const double ny = neg_quotient_for_trunc((y_og - off_sy) - a.sg.pos_y, a.sg.res, rres);
-    const double tx = -1.0 * ((x_og - a.sg.pos_x) - off_sx);
-    const double ty = -1.0 * ((y_og - a.sg.pos_y) - off_sy);
-    const bool fin = (nx > -2e9 && nx < 2e9 && ny > -2e9 && ny < 2e9);
-    const int si = fin ? (int)nx : -1, sj = fin ? (int)ny : -1;
-    const bool ok = (tx >= 0.0 && ty >= 0.0 && tx < a.sg.len_x && ty < a.sg.len_y) &&
-                    (si >= 0 && sj >= 0 && si < a.sg.rows && sj < a.sg.cols);
+    bool ok;
+    int si, sj;
+    bool have = false;
+    if (jj > 0) have = cell_estimated(a.sg, t0x + (double)jj * step_x, t0y + (double)jj * step_y, nrres, guard, ok, si, sj);
+    if (!have) {  // the first column of the run, and any cell whose estimate is too close to a source-cell boundary
+      const double Cy = (a.dg.pos_y + off_dy) + a.dg.res * (double)(-j);
+      const double x_og = (cxc - Cy * a.sin_t) + a.vx;
+      const double y_og = (cxs + Cy * a.cos_t) + a.vy;
+      double tx_, ty_;
+      ok = cell_exact(a.sg, x_og, y_og, off_sx, off_sy, rres, si, sj, tx_, ty_);
+      if (jj == 0) { t0x = tx_; t0y = ty_; }
+    }
     const size_t lin = (size_t)j * drows + i;
     float v;
     if (ok) {
@@ -103,7 +149,7 @@ constexpr int VT_J = 8;    // columns per tile: wave w handles j = w, w + 4
 __global__ __launch_bounds__(NTHREADS) void warp_batch_kernel(WarpBatchArgs a, int tiles_i) {
 #pragma clang fp contract(off)
   const int frame = blockIdx.y;
-  const double* pose = a.poses + 4 * (size_t)frame;
+  const double* pose = a.poses ? a.poses + 4 * (size_t)frame : a.pose0;  // (wave-uniform; a single frame carries its pose in the arguments)
   const double vx = pose[0], vy = pose[1], sin_t = pose[2], cos_t = pose[3];
   const int ti = blockIdx.x % tiles_i, tj = blockIdx.x / tiles_i;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -113,7 +159,10 @@ __global__ __launch_bounds__(NTHREADS) void warp_batch_kernel(WarpBatchArgs a, i
   float* dst = a.dst + frame * frame_cells;
   const double off_dx = 0.5 * a.dg.len_x - 0.5 * a.dg.res, off_dy = 0.5 * a.dg.len_y - 0.5 * a.dg.res;
   const double off_sx = 0.5 * a.sg.len_x, off_sy = 0.5 * a.sg.len_y;
-  const double rres = 1.0 / a.sg.res;
+  const double rres = 1.0 / a.sg.res, nrres = -rres;
+  const double guard = estimate_guard(a.sg, a.dg, vx, vy, rres);
+  // a lane's four rows: the centre advances by (-res cos, -res sin) from one row to the next
+  const double step_x = -a.dg.res * cos_t, step_y = -a.dg.res * sin_t;
   double cxc[4], cxs[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -130,18 +179,20 @@ __global__ __launch_bounds__(NTHREADS) void warp_batch_kernel(WarpBatchArgs a, i
     const double Cy = (a.dg.pos_y + off_dy) + a.dg.res * (double)(-j);
     const double cys = Cy * sin_t, cyc = Cy * cos_t;
     float v[4];
+    double t0x = 0.0, t0y = 0.0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const double x_og = (cxc[k] - cys) + vx;
-      const double y_og = (cxs[k] + cyc) + vy;
-      const double nx = neg_quotient_for_trunc((x_og - off_sx) - a.sg.pos_x, a.sg.res, rres);
-      const double ny = neg_quotient_for_trunc((y_og - off_sy) - a.sg.pos_y, a.sg.res, rres);
-      const double tx = -1.0 * ((x_og - a.sg.pos_x) - off_sx);
-      const double ty = -1.0 * ((y_og - a.sg.pos_y) - off_sy);
-      const bool fin = (nx > -2e9 && nx < 2e9 && ny > -2e9 && ny < 2e9);
-      const int si = fin ? (int)nx : -1, sj = fin ? (int)ny : -1;
-      const bool ok = (tx >= 0.0 && ty >= 0.0 && tx < a.sg.len_x && ty < a.sg.len_y) &&
-                      (si >= 0 && sj >= 0 && si < a.sg.rows && sj < a.sg.cols);
+      bool ok;
+      int si, sj;
+      bool have = false;
+      if (k > 0) have = cell_estimated(a.sg, t0x + (double)k * step_x, t0y + (double)k * step_y, nrres, guard, ok, si, sj);
+      if (!have) {  // the first row of the run, and any cell whose estimate is too close to a source-cell boundary
+        const double x_og = (cxc[k] - cys) + vx;
+        const double y_og = (cxs[k] + cyc) + vy;
+        double tx_, ty_;
+        ok = cell_exact(a.sg, x_og, y_og, off_sx, off_sy, rres, si, sj, tx_, ty_);
+        if (k == 0) { t0x = tx_; t0y = ty_; }
+      }
       if (ok) {
         v[k] = a.src[(size_t)sj * a.sg.rows + si];
       } else {
@@ -176,6 +227,13 @@ hipError_t launch_warp_batch(const WarpBatchArgs& a, int K, hipStream_t stream) 
 }
 
 hipError_t launch_warp(const WarpArgs& a, hipStream_t stream) {
+  if (a.dg.rows % 4 == 0) {  // four rows per lane, 16-byte stores: a quarter of the workgroups to dispatch, three of four cells by estimate
+    WarpBatchArgs b;
+    b.src = a.src; b.dst = a.dst; b.bbox = a.bbox; b.n_oob = a.n_oob; b.poses = nullptr;
+    b.pose0[0] = a.vx; b.pose0[1] = a.vy; b.pose0[2] = a.sin_t; b.pose0[3] = a.cos_t;
+    b.sg = a.sg; b.dg = a.dg;
+    return launch_warp_batch(b, 1, stream);
+  }
   const int tiles_i = (a.dg.rows + TILE_I - 1) / TILE_I, tiles_j = (a.dg.cols + TILE_J - 1) / TILE_J;
   const int n_tiles = tiles_i * tiles_j;
   if (n_tiles <= 0) return hipSuccess;
