@@ -532,6 +532,47 @@ def test_family_rule_on_measured_shapes(cilqr, oracle):
     assert (got["iters"] >= 1).all()
 
 
+@pytest.mark.parametrize("B,N,n_dyn,S,W", [(200, 50, 8, 32, 4), (1200, 50, 8, 8, 2), (33, 30, 3, 5, 2), (40, 64, 2, 4, 2), (17, 12, 5, 2, 4), (9, 20, 7, 3, 4)])
+def test_split_kernel_against_one_wavefront_per_solve(cilqr, oracle, monkeypatch, B, N, n_dyn, S, W):
+    """Sampled obstacles: W = 2 or 4 wavefronts per solve share the obstacle entries of phase L (cilqr_solve_split_kernel; the default
+    for horizons up to 64: four up to one solve per SIMD, two beyond).  Against the one-wavefront kernel (CILQR_NO_SPLIT_KERNEL): the same accept / reject path on every solve and
+    agreement to rounding (the entries of a step are summed in two interleaved halves); against the oracle on the materialised
+    scene: TIGHT.  Odd obstacle counts (the halves differ in size), horizons of 12 … 64, obstacles that turn and brake."""
+    from cilqr_amd import scenes
+    p = cilqr.default_params(N)
+    sc = scenes.make_c3(B, p, n_dyn=n_dyn, n_samples=S) if N == 50 else None
+    if sc is None:  # other horizons: the static generator's scene with moving, turning obstacles and drawn offsets
+        st = scenes.make_static(B, N, n_dyn, p, 7500 + N)
+        rng = np.random.default_rng(7500 + N)
+        pose = st["obs_pose"].reshape(B, n_dyn, N, 4).copy()
+        pose[..., 2] = rng.uniform(0.0, 6.0, (B, n_dyn, 1))
+        pose[:, 0, :, 3] += 0.01 * np.arange(N)  # one obstacle turns: the per-entry derivation of its samples
+        off = rng.normal(0.0, 1.0, (B, n_dyn, S, 3)) * scenes.POSE_SIGMA
+        mp, md, mw = scenes.materialise_samples(pose.reshape(B, n_dyn, 4 * N), st["obs_dim"], off, N)
+        sc = dict(st, M=n_dyn * S, nom_pose=pose.reshape(B, n_dyn, 4 * N), nom_dim=st["obs_dim"], offsets=off, sample_weight=1.0 / S,
+                  obs_pose=mp, obs_dim=md, obs_weight=mw)
+
+    def run(slv):
+        return slv.solve_batch_sampled(N, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["nom_pose"], sc["nom_dim"], sc["offsets"], sc["sample_weight"])
+    monkeypatch.setenv("CILQR_SPLIT_W", str(W))
+    two = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=n_dyn * S, device=0)
+    monkeypatch.delenv("CILQR_SPLIT_W")
+    monkeypatch.setenv("CILQR_NO_SPLIT_KERNEL", "1")
+    one = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=n_dyn * S, device=0)
+    monkeypatch.delenv("CILQR_NO_SPLIT_KERNEL")
+    try:
+        got, ref, again = run(two), run(one), run(two)
+    finally:
+        two.close()
+        one.close()
+    for k in ("U", "X", "J", "iters", "status"):
+        assert np.array_equal(got[k], again[k]), k
+    _compare(got, ref, 1e-11, "split kernel against one wavefront per solve")
+    idx = np.arange(min(B, 48))
+    sub = {k: (v[idx] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in sc.items()}
+    _compare({k: v[idx] for k, v in got.items()}, _oracle_batch(oracle, N, sub), TIGHT, "split kernel")
+
+
 def test_schedule_hint_changes_nothing_but_the_order(cilqr):
     """A batch beyond one solve per SIMD is dispatched longest-first by the pass counts of the previous call (same batch size,
     same stream).  Every call must return bit-identical results — the first (identity order), the second (hinted) and a third
@@ -1092,6 +1133,11 @@ def test_device_pointer_entry_points_on_a_side_stream(cilqr):
         host_plain = s.solve_batch(N, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"], sc["obs_weight"])
         host_samp = s.solve_batch_sampled(N, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["nom_pose"], sc["nom_dim"],
                                           sc["offsets"], sc["sample_weight"])
+        # (the reference loop runs on the one-wavefront kernel, the early exit on two wavefronts per solve that add a step's
+        # obstacle terms in another order: equal to rounding, test_split_kernel_…; bit for bit each against its own host call)
+        host_samp_f = s.solve_batch_sampled(N, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["nom_pose"], sc["nom_dim"],
+                                            sc["offsets"], sc["sample_weight"], flags=cilqr.FLAG_FAITHFUL_ITERS)
+        assert np.array_equal(host_samp["iters"], host_samp_f["iters"]) and np.max(np.abs(host_samp["U"] - host_samp_f["U"])) < 1e-11
         i = np.arange(200.0)
         path = np.stack([i, 0.5 * np.sin(0.05 * i)], axis=1)
         egos = np.stack([np.linspace(0, 150, B), 0.5 * np.sin(0.05 * np.linspace(0, 150, B)) + 0.2, np.full(B, 3.0), np.zeros(B)], axis=1)
@@ -1122,7 +1168,7 @@ def test_device_pointer_entry_points_on_a_side_stream(cilqr):
         side.synchronize()
     finally:
         s.close()
-    for o, U, want in ((outs[0], U1, host_plain), (outs[1], U2, host_samp), (outs[2], U3, host_samp)):
+    for o, U, want in ((outs[0], U1, host_plain), (outs[1], U2, host_samp), (outs[2], U3, host_samp_f)):
         assert np.array_equal(U.cpu().numpy(), want["U"])
         assert np.array_equal(o["X"].cpu().numpy(), want["X"]) and np.array_equal(o["J"].cpu().numpy(), want["J"])
         assert np.array_equal(o["it"].cpu().numpy(), want["iters"]) and np.array_equal(o["st"].cpu().numpy(), want["status"])

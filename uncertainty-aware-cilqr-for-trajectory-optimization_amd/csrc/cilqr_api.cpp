@@ -227,6 +227,8 @@ int cilqr_create(const cilqr_params* p, int max_batch, int max_horizon, int max_
   h->hint_off = getenv("CILQR_NO_SCHEDULE_HINT") != nullptr;
   h->pair_on = getenv("CILQR_PAIR_KERNEL") != nullptr;
   h->steal_off = getenv("CILQR_NO_LANE_SHARING") != nullptr;
+  h->split_off = getenv("CILQR_NO_SPLIT_KERNEL") != nullptr;
+  if (const char* sw = getenv("CILQR_SPLIT_W")) h->split_w = atoi(sw);  // (test hook: 2 or 4 wavefronts per solve)
   if (err == hipSuccess) err = dmalloc(&h->d_pair, (size_t)2);
   if (err == hipSuccess) err = dmalloc(&h->d_triple, (size_t)3);
   if (err == hipSuccess) err = dmalloc(&h->d_gather, (size_t)3);
@@ -422,7 +424,7 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
   a.samp_off = nullptr; a.n_samples = 0; a.samp_w = 0.0;
   a.obs_tab = h->d_obs_tab;
   a.fwd = h->d_ws;  // (the grouped family's workspace: 42·N + 12 doubles per solve ≥ the 16·(N + 1) needed here; never both at once)
-  a.order = nullptr; a.hint_passes = nullptr; a.pair = 0; a.steal = h->steal_off ? 0 : 1;
+  a.order = nullptr; a.hint_passes = nullptr; a.pair = 0; a.steal = h->steal_off ? 0 : 1; a.split = 0;
   a.redo = h->d_redo;
   a.diag = h->diag;
   a.passes = h->passes;
@@ -480,6 +482,10 @@ int cilqr_solve_batch_sampled_device(cilqr_handle* h, void* stream, int B, int N
   a.obs_tab = h->d_obs_tab;  // n_obs·N·8 doubles per solve ≤ the n_obs·n_samples·N·6 reserved for the materialised form
   a.fwd = h->d_ws;
   a.pair = 0; a.steal = 0;
+  // wavefronts per solve sharing phase L (cilqr_solve_split_kernel): four up to one solve per SIMD, where a shorter pass is all that
+  // counts, two beyond (tools/split_ab.py, profiles/r03_split_kernel.txt: B = 256 0.87 / 1.33 / 2.08 ms with 4 / 2 / 1 wavefronts,
+  // B = 1024 1.45 / 1.54 / 2.15, B = 4096 3.77 / 3.27 / 4.32, B = 8192 6.84 / 5.36 / 7.07)
+  a.split = h->split_off ? 0 : (h->split_w ? h->split_w : (B <= h->simds ? 4 : 2));
   a.redo = h->d_redo;
   a.diag = h->diag;
   a.passes = h->passes;

@@ -564,40 +564,11 @@ __device__ __forceinline__ void ab_terms(const KParams& kp, double u0, double vn
   r.q = kp.half_dt2 * sn;    // B(0,1)
 }
 
-// Constraints::get_state_cost / get_control_cost for one step (I/Constraints.cpp:145-227, 86-137; obstacles
-// I/Obstacle.cpp:39-112) plus the six non-trivial Jacobian entries at (v_{t+1}, theta_{t+1}, a_t) (I/iLQR.cpp:102-106,
-// I/Model.cpp:100-155).  (px,py,v,ct,st): state t with cos/sin of its heading; (vn,cn,sn): speed and cos/sin heading of
-// state t+1; (cx,cy): closest path sample.  `obs(m, e, w)` supplies obstacle m at this step and its weight.
-// Returns the stage cost of get_J.
-// CULL (one wavefront per solve only: the lanes of a vote are the timesteps of ONE trajectory): an entry whose barrier
-// exponent q2·c is below -64 on both ego circles for every step of the wavefront contributes less than e^-64 ≈ 1.6e-28 times
-// O(10) factors to any sum — it is skipped after the 22 instructions that establish this, before its two exponentials.  The
-// gradient and Hessian sums it would have been added to are O(1e-3 … 1e3): the omission is below 1e-26 absolute, i.e. far
-// below one ulp of anything it feeds (measured: max|ΔU| against the oracle unchanged).  NaN exponents never vote to skip.
-// LANE_EXACT (with CULL): a step at which the entry is negligible adds exactly nothing, whatever the other steps of the vote need
-// (its weight is taken as 0) — the record of a step then depends on that step alone, not on which steps share its wavefront, so
-// the two-wavefront kernel, whose votes span other sets of steps, produces the same bits (cilqr_solve.hip).
-// The uncertainty-map term (I/Constraints.cpp:188-201) is NOT added here: the kernels add it to the stored record in a loop of
-// its own (unc_cost_add — after the obstacle terms, i.e. in the reference's order of summation), which keeps its registers out of
-// the obstacle loop's allocation (inlined here it cost the table-streaming configuration a third of its speed).
-// PAIRED (with CULL): entries are taken two at a time with four entries' loads in flight — for obstacle tables streamed from
-// global memory, where it is worth 12 % (config 3 materialised: 7.6 → 6.6 ms); where the entries come from LDS the extra live
-// registers cost more than the overlap brings (config 2 +2.4 %, config 3 compact +2 %), so it is off there.
-template <bool CULL = false, bool PAIRED = false, bool LANE_EXACT = false, typename ObsAt>
-__device__ __forceinline__ double lin_step(const KParams& kp, double px, double py, double v, double ct, double st, double u0,
-                                           double u1, double vn, double cn, double sn, double cx, double cy, int M, ObsAt obs,
-                                           Rec& r) {
-  // --- tracking cost (I/Constraints.cpp:163-174)
-  const double dx = px - cx, dy = py - cy, dv = v - kp.desired_speed;
-  StepSums a;
-  a.lx0 = (2 * kp.w_pos) * dx;
-  a.lx1 = (2 * kp.w_pos) * dy;
-  const double lx2 = (2 * kp.w_vel) * dv;
-  a.h00 = kp.w_pos * 2; a.h01 = 0.0; a.h11 = kp.w_pos * 2;
-  const double J = stage_cost(kp, dx, dy, dv, u0, u1);
-
-  // --- obstacles (I/Constraints.cpp:177-187, I/Obstacle.cpp:39-112)
-  const ObsConsts oc = make_obs_consts(kp, px, py, ct, st);
+// The obstacle terms of one step (I/Constraints.cpp:177-187, I/Obstacle.cpp:39-112) added to the sums `a`, entries 0 … M-1 of `obs`
+// in order: the loop of lin_step, on its own so that a second wavefront can evaluate a share of a step's entries
+// (cilqr_solve.hip, cilqr_solve_split_kernel).  CULL, PAIRED, LANE_EXACT: see lin_step.
+template <bool CULL, bool PAIRED, bool LANE_EXACT, typename ObsAt>
+__device__ __forceinline__ void obstacle_loop(const ObsConsts& oc, int M, ObsAt obs, StepSums& a) {
   using Prep = ObsPrep;
   auto prep = [&](const ObsEntry& e, Prep& p) { obs_prep(oc, e, p); };
   // the wave-wide vote of CULL: false when the entry is negligible at every step of the wavefront
@@ -666,6 +637,43 @@ __device__ __forceinline__ double lin_step(const KParams& kp, double px, double 
     }
     if (m < M && va) add_entry(ea, wa);
   }
+
+}
+
+// Constraints::get_state_cost / get_control_cost for one step (I/Constraints.cpp:145-227, 86-137; obstacles
+// I/Obstacle.cpp:39-112) plus the six non-trivial Jacobian entries at (v_{t+1}, theta_{t+1}, a_t) (I/iLQR.cpp:102-106,
+// I/Model.cpp:100-155).  (px,py,v,ct,st): state t with cos/sin of its heading; (vn,cn,sn): speed and cos/sin heading of
+// state t+1; (cx,cy): closest path sample.  `obs(m, e, w)` supplies obstacle m at this step and its weight.
+// Returns the stage cost of get_J.
+// CULL (one wavefront per solve only: the lanes of a vote are the timesteps of ONE trajectory): an entry whose barrier
+// exponent q2·c is below -64 on both ego circles for every step of the wavefront contributes less than e^-64 ≈ 1.6e-28 times
+// O(10) factors to any sum — it is skipped after the 22 instructions that establish this, before its two exponentials.  The
+// gradient and Hessian sums it would have been added to are O(1e-3 … 1e3): the omission is below 1e-26 absolute, i.e. far
+// below one ulp of anything it feeds (measured: max|ΔU| against the oracle unchanged).  NaN exponents never vote to skip.
+// LANE_EXACT (with CULL): a step at which the entry is negligible adds exactly nothing, whatever the other steps of the vote need
+// (its weight is taken as 0) — the record of a step then depends on that step alone, not on which steps share its wavefront, so
+// the two-wavefront kernel, whose votes span other sets of steps, produces the same bits (cilqr_solve.hip).
+// The uncertainty-map term (I/Constraints.cpp:188-201) is NOT added here: the kernels add it to the stored record in a loop of
+// its own (unc_cost_add — after the obstacle terms, i.e. in the reference's order of summation), which keeps its registers out of
+// the obstacle loop's allocation (inlined here it cost the table-streaming configuration a third of its speed).
+// PAIRED (with CULL): entries are taken two at a time with four entries' loads in flight — for obstacle tables streamed from
+// global memory, where it is worth 12 % (config 3 materialised: 7.6 → 6.6 ms); where the entries come from LDS the extra live
+// registers cost more than the overlap brings (config 2 +2.4 %, config 3 compact +2 %), so it is off there.
+template <bool CULL = false, bool PAIRED = false, bool LANE_EXACT = false, typename ObsAt>
+__device__ __forceinline__ double lin_step(const KParams& kp, double px, double py, double v, double ct, double st, double u0,
+                                           double u1, double vn, double cn, double sn, double cx, double cy, int M, ObsAt obs,
+                                           Rec& r) {
+  // --- tracking cost (I/Constraints.cpp:163-174)
+  const double dx = px - cx, dy = py - cy, dv = v - kp.desired_speed;
+  StepSums a;
+  a.lx0 = (2 * kp.w_pos) * dx;
+  a.lx1 = (2 * kp.w_pos) * dy;
+  const double lx2 = (2 * kp.w_vel) * dv;
+  a.h00 = kp.w_pos * 2; a.h01 = 0.0; a.h11 = kp.w_pos * 2;
+  const double J = stage_cost(kp, dx, dy, dv, u0, u1);
+
+  // --- obstacles (I/Constraints.cpp:177-187, I/Obstacle.cpp:39-112)
+  obstacle_loop<CULL, PAIRED, LANE_EXACT>(make_obs_consts(kp, px, py, ct, st), M, obs, a);
 
   // --- control cost (I/Constraints.cpp:110-131)
   double a1, a2, a3, a4;

@@ -71,6 +71,8 @@ struct SolveArgs {
   int32_t pair;
   // grouped family: 1 = in phase L the lanes of a wavefront's finished solves take steps of the unfinished ones (cilqr_solve_groups.hip)
   int32_t steal;
+  // sampled obstacles: 1 = two wavefronts per solve share the obstacle entries of phase L (cilqr_solve.hip, cilqr_solve_split_kernel)
+  int32_t split;
   KParams kp;
   UncArgs unc;
 };

@@ -141,6 +141,7 @@ struct SampledObstacles {
   int N, S, n_obs;
   double w;
   int o, s;
+  int o_stride;                            // 1; 2 where two wavefronts share a solve's obstacles (cilqr_solve_split_kernel)
   bool far;                                // the obstacle in use is negligible at every step of this wavefront (see below)
   const double* rmax;                      // LDS [o]: largest |(dx, dy)| over the obstacle's samples; then [n_obs + o]: constant-shape flag
   bool cshape;                             // the obstacle in use keeps heading, speed and dimensions over the horizon (see the prologue)
@@ -156,7 +157,7 @@ struct SampledObstacles {
   __device__ __forceinline__ bool operator()(int, ObsEntry& e, double& wout) {
     if (s == 0) {
       x = nx; y = ny; c0 = nc0; s0 = ns0; vt = nvt; ha = nha; hb = nhb;
-      if (o + 1 < n_obs) request(o + 1);
+      if (o + o_stride < n_obs) request(o + o_stride);
       // Whole-obstacle test before any per-sample work.  Every sample's centre is within R = rmax[o] of the nominal one
       // and both its semi-axes are at most A = max(ha, hb) + |vt| whatever its heading, so d'Pd ≥ ((D - R)/A)² for an ego
       // circle at distance D from the nominal centre; q2·(1 - d'Pd) ≤ -64 follows from D ≥ R + A·sqrt(1 + 64/q2).  If that
@@ -170,7 +171,7 @@ struct SampledObstacles {
       cshape = rmax[n_obs + o] != 0.0;  // wave-uniform
     }
     if (far) {
-      if (++s == S) { s = 0; ++o; }
+      if (++s == S) { s = 0; o += o_stride; }
       return false;
     }
     const double2* q = reinterpret_cast<const double2*>(off + ((size_t)o * S + s) * OFFF);
@@ -188,7 +189,7 @@ struct SampledObstacles {
     e.ox = x + d.x;
     e.oy = y + d.y;
     wout = w;
-    if (++s == S) { s = 0; ++o; }
+    if (++s == S) { s = 0; o += o_stride; }
     return true;
   }
 };
@@ -200,18 +201,87 @@ struct SampledSource {
   const double* X;  // LDS trajectory (XR doubles per step)
   int N, S, n_obs;
   double w, ego_front, ego_rear, kf, kr;
+  int o_first = 0, o_stride = 1;  // this source's share of the obstacles: o_first, o_first + o_stride, …
   __device__ __forceinline__ SampledObstacles at(int t) const {
     SampledObstacles a;
     a.nom = nom + (size_t)t * NOMF; a.off = off; a.N = N; a.S = S; a.n_obs = n_obs; a.w = w;
-    a.o = 0; a.s = 0; a.far = false; a.cshape = false; a.rmax = rmax;
+    a.o = o_first; a.o_stride = o_stride; a.s = 0; a.far = false; a.cshape = false; a.rmax = rmax;
     const double* xr = X + t * XR;
     a.fx = xr[0] + xr[4] * ego_front; a.fy = xr[1] + xr[5] * ego_front;
     a.rx = xr[0] - xr[4] * ego_rear; a.ry = xr[1] - xr[5] * ego_rear;
     a.kf = kf; a.kr = kr;
-    a.request(0);
+    if (o_first < n_obs) a.request(o_first);
     return a;
   }
 };
+
+// Prologue of the sampled-obstacle mode (TAB = 2), by NT threads of the workgroup (whole wavefronts): nominal records, the
+// constant-shape flags, offset records, largest sample displacement per obstacle.
+template <int NT>
+__device__ __forceinline__ void sampled_prologue(const SolveArgs& a, const KParams& kp, int b, int N, int M, double* tab, double* off, double* rmax) {
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+  for (int m = wave; m < M; m += NT / WAVE) {  // nominal records: what I/Obstacle.cpp:41-62 needs of (obstacle, step) before the sample offset
+    for (int t = lane; t < N; t += WAVE) {
+      const double* pose = a.obs_pose + (((size_t)b * M + m) * N + t) * 4;
+      const double* dim = a.obs_dim + (((size_t)b * M + m) * N + t) * 2;
+      double sn, cs;
+      sincos(pose[3], &sn, &cs);
+      double* o = tab + ((size_t)m * N + t) * NOMF;
+      o[0] = pose[0]; o[1] = pose[1]; o[2] = cs; o[3] = sn; o[4] = pose[2] * kp.t_safe;
+      o[5] = dim[0] / 2.0 + kp.s_safe_a + kp.ego_rad;
+      o[6] = dim[1] / 2.0 + kp.s_safe_b + kp.ego_rad + 1;
+      o[7] = 0.0;
+    }
+  }
+  // An obstacle that keeps its heading, speed and dimensions over the horizon (a vehicle driving straight: every obstacle of
+  // the benchmark) gives each of its samples a heading and semi-axes that do not depend on the step: they are derived here,
+  // once per solve (same arithmetic as the per-entry derivation in SampledObstacles: bit-identical results), instead of 22
+  // instructions per entry, step and iteration.  Flag per obstacle behind rmax.
+  for (int m = wave; m < M; m += NT / WAVE) {
+    bool same = true;
+    const double* pose0 = a.obs_pose + ((size_t)b * M + m) * N * 4;
+    const double* dim0 = a.obs_dim + ((size_t)b * M + m) * N * 2;
+    for (int t = lane; t < N; t += WAVE) {
+      const double* pose = pose0 + (size_t)t * 4;
+      const double* dim = dim0 + (size_t)t * 2;
+      same = same && pose[2] == pose0[2] && pose[3] == pose0[3] && dim[0] == dim0[0] && dim[1] == dim0[1];
+    }
+    const bool all_same = __builtin_amdgcn_ballot_w64(!same) == 0;
+    if (lane == 0) rmax[M + m] = all_same ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  const int n_off = M * a.n_samples;
+  for (int i = tid; i < n_off; i += NT) {
+    const double* q = a.samp_off + ((size_t)b * n_off + i) * 3;
+    double sn, cs;
+    sincos(q[2], &sn, &cs);
+    double* o = off + (size_t)i * OFFF;
+    o[0] = q[0]; o[1] = q[1];
+    const int m = i / a.n_samples;
+    if (rmax[M + m] != 0.0) {
+      const double* pose0 = a.obs_pose + ((size_t)b * M + m) * N * 4;
+      const double* dim0 = a.obs_dim + ((size_t)b * M + m) * N * 2;
+      double s0, c0;
+      sincos(pose0[3], &s0, &c0);  // the nominal record's own cos / sin
+      const double vt = pose0[2] * kp.t_safe;
+      const double ha = dim0[0] / 2.0 + kp.s_safe_a + kp.ego_rad, hb = dim0[1] / 2.0 + kp.s_safe_b + kp.ego_rad + 1;
+      const double co = c0 * cs - s0 * sn, so = s0 * cs + c0 * sn;
+      const double ra = rcp_newton(ha + fabs(vt * co)), rb = rcp_newton(hb + fabs(vt * so));  // I/Obstacle.cpp:42-43
+      o[2] = co; o[3] = so; o[4] = ra * ra; o[5] = rb * rb;
+    } else {
+      o[2] = cs; o[3] = sn; o[4] = 0.0; o[5] = 0.0;
+    }
+  }
+  for (int o = tid; o < M; o += NT) {  // largest sample displacement per obstacle (SampledObstacles' whole-obstacle test)
+    double r2 = 0.0;
+    for (int q = 0; q < a.n_samples; ++q) {
+      const double* f = a.samp_off + ((size_t)b * n_off + (size_t)o * a.n_samples + q) * 3;
+      const double d2 = f[0] * f[0] + f[1] * f[1];
+      r2 = fmax(r2, d2 == d2 ? d2 : __builtin_huge_val());
+    }
+    rmax[o] = sqrt(r2);
+  }
+}
 
 // Shader-clock stamp of the diagnostic instantiation, ordered by the compiler behind the value it names (the hardware issues in
 // order: a stamp is taken when everything before it has ISSUED, and an instruction that needs an unfinished result stalls there).
@@ -786,67 +856,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
 
   const double* wts = (TAB != 2 && a.obs_weight) ? a.obs_weight + (size_t)b * M : nullptr;
   if (TAB == 2) {
-    for (int m = 0; m < M; ++m) {  // nominal records: what I/Obstacle.cpp:41-62 needs of (obstacle, step) before the sample offset
-      for (int t = lane; t < N; t += WAVE) {
-        const double* pose = a.obs_pose + (((size_t)b * M + m) * N + t) * 4;
-        const double* dim = a.obs_dim + (((size_t)b * M + m) * N + t) * 2;
-        double sn, cs;
-        sincos(pose[3], &sn, &cs);
-        double* o = tab + ((size_t)m * N + t) * NOMF;
-        o[0] = pose[0]; o[1] = pose[1]; o[2] = cs; o[3] = sn; o[4] = pose[2] * kp.t_safe;
-        o[5] = dim[0] / 2.0 + kp.s_safe_a + kp.ego_rad;
-        o[6] = dim[1] / 2.0 + kp.s_safe_b + kp.ego_rad + 1;
-        o[7] = 0.0;
-      }
-    }
-    // An obstacle that keeps its heading, speed and dimensions over the horizon (a vehicle driving straight: every obstacle of
-    // the benchmark) gives each of its samples a heading and semi-axes that do not depend on the step: they are derived here,
-    // once per solve (same arithmetic as the per-entry derivation in SampledObstacles: bit-identical results), instead of 22
-    // instructions per entry, step and iteration.  Flag per obstacle behind rmax.
-    for (int m = 0; m < M; ++m) {
-      bool same = true;
-      const double* pose0 = a.obs_pose + ((size_t)b * M + m) * N * 4;
-      const double* dim0 = a.obs_dim + ((size_t)b * M + m) * N * 2;
-      for (int t = lane; t < N; t += WAVE) {
-        const double* pose = pose0 + (size_t)t * 4;
-        const double* dim = dim0 + (size_t)t * 2;
-        same = same && pose[2] == pose0[2] && pose[3] == pose0[3] && dim[0] == dim0[0] && dim[1] == dim0[1];
-      }
-      const bool all_same = __builtin_amdgcn_ballot_w64(!same) == 0;
-      if (lane == 0) rmax[M + m] = all_same ? 1.0 : 0.0;
-    }
-    __syncthreads();
-    const int n_off = M * a.n_samples;
-    for (int i = lane; i < n_off; i += WAVE) {
-      const double* q = a.samp_off + ((size_t)b * n_off + i) * 3;
-      double sn, cs;
-      sincos(q[2], &sn, &cs);
-      double* o = off + (size_t)i * OFFF;
-      o[0] = q[0]; o[1] = q[1];
-      const int m = i / a.n_samples;
-      if (rmax[M + m] != 0.0) {
-        const double* pose0 = a.obs_pose + ((size_t)b * M + m) * N * 4;
-        const double* dim0 = a.obs_dim + ((size_t)b * M + m) * N * 2;
-        double s0, c0;
-        sincos(pose0[3], &s0, &c0);  // the nominal record's own cos / sin
-        const double vt = pose0[2] * kp.t_safe;
-        const double ha = dim0[0] / 2.0 + kp.s_safe_a + kp.ego_rad, hb = dim0[1] / 2.0 + kp.s_safe_b + kp.ego_rad + 1;
-        const double co = c0 * cs - s0 * sn, so = s0 * cs + c0 * sn;
-        const double ra = rcp_newton(ha + fabs(vt * co)), rb = rcp_newton(hb + fabs(vt * so));  // I/Obstacle.cpp:42-43
-        o[2] = co; o[3] = so; o[4] = ra * ra; o[5] = rb * rb;
-      } else {
-        o[2] = cs; o[3] = sn; o[4] = 0.0; o[5] = 0.0;
-      }
-    }
-    for (int o = lane; o < M; o += WAVE) {  // largest sample displacement per obstacle (SampledObstacles' whole-obstacle test)
-      double r2 = 0.0;
-      for (int q = 0; q < a.n_samples; ++q) {
-        const double* f = a.samp_off + ((size_t)b * n_off + (size_t)o * a.n_samples + q) * 3;
-        const double d2 = f[0] * f[0] + f[1] * f[1];
-        r2 = fmax(r2, d2 == d2 ? d2 : __builtin_huge_val());
-      }
-      rmax[o] = sqrt(r2);
-    }
+    sampled_prologue<WAVE>(a, kp, b, N, M, tab, off, rmax);
   } else {
     for (int m = 0; m < M; ++m) {  // obstacle table, I/Obstacle.cpp:41-62
       for (int t = lane; t < N; t += WAVE) {
@@ -1357,6 +1367,197 @@ __global__ __launch_bounds__(2 * WAVE) void cilqr_solve_pair_kernel(SolveArgs a)
 #undef CILQR_STAMP
 }
 
+// ==== Sampled obstacles, two wavefronts per solve (BASELINE config 3) =============================================================
+// With hundreds of obstacle entries per step phase L is 80 % of a pass (config 3: L 152 k ticks against R 19.6 k + F 21.9 k), and a
+// batch of more solves than SIMDs ends when its LONGEST solve does: 20 passes × 193 k ticks, however well the rest of the batch
+// keeps the chip busy — on a planner's tick sequence the launch lasts about twice what its work alone would take
+// (profiles/r03_schedule_hint_ticks.txt; pass counts of the previous tick predict too little for the dispatch order to help).
+// Here a solve is a workgroup of two wavefronts that share phase L: both take lanes = timesteps, wavefront 0 the obstacles
+// 0, 2, 4, … of every step (and everything else of the step: closest sample, tracking, control barrier, Jacobians), wavefront 1
+// the obstacles 1, 3, 5, …; wavefront 1 leaves its five sums per step in LDS, wavefront 0 adds them to its own behind one
+// barrier and goes on alone through R and F.  A pass is then ≈ 76 k + 41 k ticks instead of 193 k, the work the same: four
+// workgroups of two wavefronts per CU instead of seven of one (the kernel's ≈ 240 vector registers allow eight wavefronts).
+// Sums: the entries of a step are added in two interleaved halves instead of one run — results differ from the one-wavefront
+// kernel in the last bits (tolerance against the oracle unchanged), deterministic, independent of the batch around the solve.
+// Horizons up to 64 (one step per lane: wavefront 0 holds its step's record in registers across the barrier).
+// W = wavefronts per solve (2 or 4): wavefront w takes the obstacles w, w + W, …; wavefront 0 adds the others' sums in the order 1, 2, 3.
+template <int W>
+__global__ __launch_bounds__(W * WAVE) void cilqr_solve_split_kernel(SolveArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  if ((int)blockIdx.x >= a.B) return;
+  const int b = __builtin_amdgcn_readfirstlane(a.order ? a.order[blockIdx.x] : (int)blockIdx.x);
+  if (b >= a.B) return;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const KParams kp = a.kp;
+  const int N = a.N, M = a.M, S = kp.n_samples, NSMP = a.n_samples;
+  double* samp = lds;
+  double* Xa = samp + ((S + 1) & ~1);
+  double* Ua = Xa + (N + 1) * XR;
+  double* rec = Ua + 2 * N;
+  double* cst = rec + N * RECF;
+  double* off = cst + RCST;
+  double* rmax = off + (size_t)M * NSMP * OFFF;
+  double* part = rmax + 2 * M;                        // [W - 1][N][5]: the other wavefronts' sums of a step's obstacle terms
+  double* ctl = part + (((W - 1) * 5 * N + 1) & ~1);  // command word
+  int* const cmd = reinterpret_cast<int*>(ctl);
+  double* tab = a.obs_tab + (size_t)b * M * NOMF * N;
+
+  // ---- prologue, both wavefronts -----------------------------------------------------------------------------------------------
+  SampleGrid grid;
+  make_sample_grid(grid, a.xplan_fl[2 * b], a.xplan_fl[2 * b + 1], S);
+  {
+    const double* pc = a.poly + (size_t)b * CILQR_POLY_COEFFS;
+    for (int s = tid; s < S; s += W * WAVE) {
+      double xs;
+      sample_xy(grid, pc, s, xs, samp[s]);
+    }
+  }
+  const double* Ug = a.U + (size_t)b * 2 * N;
+  for (int i = tid; i < 2 * N; i += W * WAVE) Ua[i] = Ug[i];
+  if (tid < 16 && (tid & 7) < 5) cst[(tid & 7) + (tid >> 3) * RECF] = (tid & 7) == 0 ? 0.0 : (tid & 7) == 1 ? 1.0 : (tid & 7) == 2 ? kp.dt : (tid & 7) == 3 ? kp.w_vel * 2 : 2.0;
+  if (tid == 0) cmd[0] = 0;
+  sampled_prologue<W * WAVE>(a, kp, b, N, M, tab, off, rmax);
+  __syncthreads();
+  bool handover = false;
+  if (wave == 0) {
+    {  // largest step between adjacent path samples in y: closest_sample's second window (cilqr_device.hpp)
+      double m = 0.0;
+      for (int q = lane; q + 1 < S; q += WAVE) {
+        const double d = fabs(samp[q + 1] - samp[q]);
+        m = fmax(m, d == d ? d : __builtin_huge_val());
+      }
+      grid.dmax = wave_max_uniform(m);
+    }
+    handover = !rollout_fast(kp, N, a.x0 + (size_t)b * 4, Ua, Xa);  // nominal rollout, I/iLQR.cpp:51-62
+    if (handover && lane == 0) *reinterpret_cast<volatile int*>(cmd) = CMD_EXIT;
+  }
+  __syncthreads();  // the trajectory is in LDS
+
+  const int t = lane;
+  const bool act = t < N;
+  const int n_mine = (M - wave + W - 1) / W;  // obstacles wave, wave + W, … < M
+  if (wave != 0) {
+    // ---- wavefronts 1 … W-1: their share of every step's obstacle terms, pass after pass ------------------------------------------------
+    for (;;) {
+      if (*reinterpret_cast<volatile int*>(cmd) == CMD_EXIT) break;
+      if (act) {
+        const KParams kpl = phase_params();
+        const double* xr = Xa + t * XR;
+        SampledSource src{tab, off, rmax, Xa, N, NSMP, M, a.samp_w, kpl.ego_front, kpl.ego_rear,
+                          sqrt(1.0 + 64.0 / kpl.q2_front), sqrt(1.0 + 64.0 / kpl.q2_rear)};
+        src.o_first = wave; src.o_stride = W;
+        StepSums s5{0.0, 0.0, 0.0, 0.0, 0.0};
+        obstacle_loop<true, false, false>(make_obs_consts(kpl, xr[0], xr[1], xr[4], xr[5]), n_mine * NSMP, src.at(t), s5);
+        double* q = part + ((size_t)(wave - 1) * N + t) * 5;
+        q[0] = s5.lx0; q[1] = s5.lx1; q[2] = s5.h00; q[3] = s5.h01; q[4] = s5.h11;
+      }
+      __syncthreads();  // A: the sums are in LDS
+      __syncthreads();  // B: wavefront 0 has decided, and, going on, has written the next trajectory
+    }
+    return;
+  }
+
+  // ---- wavefront 0 ---------------------------------------------------------------------------------------------------------------
+  double J_old = DBL_MAX, lamb = 1.0, J_new = 0.0;
+  int iters = 0, status = CILQR_EXIT_MAX_ITER, n_pass = 0;
+  bool j_valid = false;
+  const int max_it = kp.max_iterations;
+  for (int it = 0; it < max_it && !handover; ++it) {
+    ++iters;
+    {  // phase L: this wavefront's share, then wavefront 1's sums on top
+      const KParams kpl = phase_params();
+      Rec c{};
+      double Jt = 0.0;
+      if (act) {
+        const double* xr = Xa + t * XR;
+        const double* xn = Xa + (t + 1) * XR;
+        const int cs = closest_sample(S, grid, xr[0], xr[1], LdsSamples{samp, grid.xf, grid.dxs});
+        SampledSource src{tab, off, rmax, Xa, N, NSMP, M, a.samp_w, kpl.ego_front, kpl.ego_rear,
+                          sqrt(1.0 + 64.0 / kpl.q2_front), sqrt(1.0 + 64.0 / kpl.q2_rear)};
+        src.o_first = 0; src.o_stride = W;
+        Jt = lin_step<true, false, false>(kpl, xr[0], xr[1], xr[2], xr[4], xr[5], Ua[2 * t], Ua[2 * t + 1], xn[2], xn[4], xn[5],
+                                           fma(grid.dxs, (double)cs, grid.xf), samp[cs], n_mine * NSMP, src.at(t), c);
+      }
+      __syncthreads();  // A
+      if (act) {
+#pragma unroll
+        for (int w = 1; w < W; ++w) {
+          const double* q = part + ((size_t)(w - 1) * N + t) * 5;
+          c.lx0 += q[0]; c.lx1 += q[1]; c.l00 += q[2]; c.l01 += q[3]; c.l11 += q[4];
+        }
+        double* r = rec + t * RECF;
+        const double ih = 2.0 / kpl.dt;  // production records: acceleration in units of (dt/2)·u0 (riccati_mfma)
+        r[0] = c.lx0; r[1] = c.lx1; r[2] = c.lx2; r[3] = c.l00; r[4] = c.l01; r[5] = c.l11;
+        r[6] = c.lu0 * ih; r[7] = c.lu1; r[8] = c.luu0 * (ih * ih); r[9] = c.luu1;
+        r[10] = c.al; r[11] = c.be; r[12] = c.ga; r[13] = c.de;
+      }
+      J_new = wave_sum_uniform(Jt);
+      j_valid = true;
+    }
+    const bool accept = J_new < J_old;
+    bool stop = false;
+    if (!accept) {
+      if (J_new != J_new) {
+        status = CILQR_EXIT_NUMERIC;
+      } else {
+        for (;;) {
+          lamb = lamb * kp.lamb_factor;
+          if (lamb > kp.lamb_max) { status = CILQR_EXIT_LAMBDA_MAX; break; }
+          if (++it >= max_it) { status = CILQR_EXIT_MAX_ITER; break; }
+          ++iters;
+        }
+      }
+      stop = true;
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the records are in LDS (one wavefront reads what its own lanes wrote)
+      if (!riccati_mfma<false, false>(N, rec, rec, nullptr, cst, 2.0 / kp.dt, lamb, nullptr)) {
+        handover = true;
+        stop = true;
+      } else {
+        ++n_pass;
+        if (!forward_fast<RECF>(KParams(phase_params()), N, Xa, Ua, rec, Xa, Ua)) {
+          handover = true;
+          stop = true;
+        } else {
+          j_valid = false;
+          lamb = lamb / kp.lamb_factor;
+          if (fabs(J_new - J_old) < kp.tolerance) { status = CILQR_EXIT_TOLERANCE; stop = true; }
+          J_old = J_new;
+          if (it + 1 >= max_it) stop = true;
+        }
+      }
+    }
+    if (stop && lane == 0) *reinterpret_cast<volatile int*>(cmd) = CMD_EXIT;
+    __syncthreads();  // B
+    if (stop) break;
+  }
+
+  int32_t* const hint = phase_args().hint_passes;
+  if (lane == 0) {
+    phase_args().redo[b] = handover ? 1 : 0;
+    if (handover && hint) hint[b] = 63;
+  }
+  if (handover) return;  // outputs (and the in/out U) untouched: the GENERAL kernel starts from the same inputs
+
+  // ---- epilogue: X_result / U_result (:243-244) ------------------------------------------------------------------------------
+  const SolveArgs ae = phase_args();
+  double* Uo = ae.U + (size_t)b * 2 * N;
+  for (int i = lane; i < 2 * N; i += WAVE) Uo[i] = Ua[i];
+  double* Xg = ae.X_out + (size_t)b * 4 * (N + 1);
+  for (int i = lane; i < 4 * (N + 1); i += WAVE) Xg[i] = Xa[(i >> 2) * XR + (i & 3)];
+  if (ae.J_out) {
+    if (!j_valid) J_new = wave_sum_uniform(cost_only(ae.kp, N, lane, samp, S, grid, Xa, Ua));
+    if (lane == 0) ae.J_out[b] = J_new;
+  }
+  if (lane == 0) {
+    if (ae.iters_out) ae.iters_out[b] = iters;
+    if (ae.status_out) ae.status_out[b] = status;
+    if (ae.passes) ae.passes[b] = n_pass;
+    if (ae.hint_passes) ae.hint_passes[b] = n_pass;
+  }
+}
+
 __global__ void quu_inverse_kernel(int n, const double* q, const double* lamb, double* out, int general) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -1483,6 +1684,18 @@ hipError_t launch_solve_wave(const SolveArgs& a, hipStream_t stream) {
   if (a.n_samples > 0) {  // sampled obstacles: offset records in LDS, nominal records in the global workspace
     const size_t extra = solve_sampled_lds_bytes(a.M, a.n_samples);
     if (lds + extra > SOLVE_LDS_MAX) return hipErrorInvalidValue;  // checked by the caller
+    if (a.split >= 2 && a.N <= WAVE && a.M >= a.split && !a.diag && !a.unc.layer && (a.flags & CILQR_FLAG_FAITHFUL_ITERS) == 0) {
+      // a.split wavefronts per solve share phase L (cilqr_solve_split_kernel); the GENERAL kernel of the one-wavefront family behind
+      const int W = a.split >= 4 ? 4 : 2;
+      const size_t lds_fast = core_lds_bytes(a.N, a.kp.n_samples, true) + extra + ((((size_t)(W - 1) * 5 * a.N + 1) & ~(size_t)1) + 2) * sizeof(double);
+      const size_t lds_general = core_lds_bytes(a.N, a.kp.n_samples, false) + extra;
+      if (lds_fast <= 64 * 1024 && lds_general <= 64 * 1024) {
+        if (W == 4) hipLaunchKernelGGL((cilqr_solve_split_kernel<4>), dim3(a.B), dim3(4 * WAVE), lds_fast, stream, a);
+        else hipLaunchKernelGGL((cilqr_solve_split_kernel<2>), dim3(a.B), dim3(2 * WAVE), lds_fast, stream, a);
+        hipLaunchKernelGGL((cilqr_solve_kernel<false, 2, true, false>), dim3(a.B), dim3(WAVE), lds_general, stream, a);
+        return hipGetLastError();
+      }
+    }
     return a.diag ? launch_pair<true, 2>(a, extra, stream) : launch_pair<false, 2>(a, extra, stream);
   }
   if (lds > SOLVE_LDS_MAX) return hipErrorInvalidValue;  // checked by the caller
