@@ -801,6 +801,7 @@ def main():
                                              "solves are dispatched longest-first by the previous call's pass counts; without_hint = same "
                                              "launch, dispatch in index order")}
             if use_ticks:  # the repeated-batch figure, as a labelled note: the last tick solved five times over
+                cur.update(tick_in[-1])  # (also what the parity figure below compares: U then holds the LAST tick's results)
                 r0 = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
                 r1 = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
                 for q in range(5):
