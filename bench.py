@@ -748,6 +748,9 @@ def main():
         flops_solve = mean_lin * N * (6 * 200 + 100 * M) + mean_passes * N * 800
         # which kernel family the library picks for this shape: asked, not restated (cilqr_solve_family)
         lanes = 64 if sampled else solver.solve_family(B, N, M)
+        kernel_name = "cilqr_solve_kernel" if lanes == 64 else "cilqr_solve_groups_fast<%d>" % lanes
+        if sampled and solver.solve_sampled_wavefronts(B, N, n_dyn) > 1:
+            kernel_name = "cilqr_solve_split_kernel<%d>" % solver.solve_sampled_wavefronts(B, N, n_dyn)
         traffic, traffic_tag = (None, None) if (args.workload == "c3" and args.materialised) else recorded_traffic(args.workload, B)
         out = {
             "metric": "CILQR solves/sec (N=%d, batch B)" % N, "value": value, "unit": "solves/s", "n_gpus": world,
@@ -757,7 +760,7 @@ def main():
                                    + ", inputs resident in HBM, + min-cost selection",
                        "batch_per_gpu": B, "horizon": N, "obstacles": M, "mean_reference_iterations": mean_iters,
                        "parallelism": "scene-sharded x%d, one ncclAllGather of 24 B per rank behind cilqr_argmin_global_device" % world},
-            "roofline": {"bound": "hbm", "kernel": "cilqr_solve_kernel" if lanes == 64 else "cilqr_solve_groups_fast<%d>" % lanes,
+            "roofline": {"bound": "hbm", "kernel": kernel_name,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_tag,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch,

@@ -368,6 +368,10 @@ int cilqr_set_pass_count_buffer(cilqr_handle* h, int32_t* dev_buf);
  * wavefront.  The same rule cilqr_solve_batch(_device) applies (CILQR_FORCE_G in the environment at create overrides it);
  * measurement tools label their figures with it instead of restating the rule.  Negative: error code. */
 int cilqr_solve_family(const cilqr_handle* h, int B, int N, int M);
+/* The same for cilqr_solve_batch_sampled(_device): how many wavefronts share a solve's phase L on this handle — 1 (one wavefront
+ * per solve: horizons beyond 64, a set uncertainty map, CILQR_NO_SPLIT_KERNEL), 2 or 4 (cilqr_solve_split_kernel, DESIGN.md
+ * §4.1c).  CILQR_FLAG_FAITHFUL_ITERS always runs on one.  Negative: error code. */
+int cilqr_solve_sampled_wavefronts(const cilqr_handle* h, int B, int N, int n_obs);
 
 /* Test hook: runs the kernels' own regularised Q_uu inverse (I/iLQR.cpp:155-175) on n column-major 2×2 matrices (host
  * buffers).  general = 0: the positive-semi-definite form of the production kernel; 1: the eigenvalue-clamping form of the

@@ -101,6 +101,14 @@ static int pick_group_lanes(const cilqr_handle* h, int B, int N, int M) {
   return G;
 }
 
+// Sampled obstacles: wavefronts per solve that share phase L (0: the one-wavefront kernel); the launcher falls back to one where
+// the split kernel does not apply (N > 64, fewer obstacles than wavefronts, a map set, the reference-loop mode).
+static int pick_split_wavefronts(const cilqr_handle* h, int B) {
+  if (h->split_off) return 0;
+  if (h->split_w) return h->split_w;
+  return B <= h->simds ? 4 : 2;
+}
+
 // The one-wavefront-per-solve family with a schedule hint.  A batch of more solves than SIMDs is dispatched in workgroup order,
 // and its launch ends when the last workgroup does: a 20-pass solve that starts among the last costs its full length on top of
 // everything else (config-2 scenes at B = 4096: 0.91 ms as given, 0.53 ms with the longest solves first; config 3: 3.8 → 2.4 ms,
@@ -408,6 +416,13 @@ int cilqr_solve_family(const cilqr_handle* h, int B, int N, int M) {
   return pick_group_lanes(h, B, N, M);
 }
 
+int cilqr_solve_sampled_wavefronts(const cilqr_handle* h, int B, int N, int n_obs) {
+  if (!h || B < 0 || N < 1 || n_obs < 1) return fail(CILQR_ERR_ARG, "cilqr_solve_sampled_wavefronts: bad argument");
+  const int w = pick_split_wavefronts(h, B);
+  if (w < 2 || N > 64 || n_obs < w || h->unc.layer || h->diag) return 1;
+  return w >= 4 ? 4 : 2;
+}
+
 int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M, const double* x0, double* U,
                              const double* poly, const double* xplan_fl, const double* obs_pose, const double* obs_dim,
                              const double* obs_weight, double* X_out, double* J_out, int32_t* iters_out,
@@ -485,7 +500,7 @@ int cilqr_solve_batch_sampled_device(cilqr_handle* h, void* stream, int B, int N
   // wavefronts per solve sharing phase L (cilqr_solve_split_kernel): four up to one solve per SIMD, where a shorter pass is all that
   // counts, two beyond (tools/split_ab.py, profiles/r03_split_kernel.txt: B = 256 0.87 / 1.33 / 2.08 ms with 4 / 2 / 1 wavefronts,
   // B = 1024 1.45 / 1.54 / 2.15, B = 4096 3.77 / 3.27 / 4.32, B = 8192 6.84 / 5.36 / 7.07)
-  a.split = h->split_off ? 0 : (h->split_w ? h->split_w : (B <= h->simds ? 4 : 2));
+  a.split = pick_split_wavefronts(h, B);
   a.redo = h->d_redo;
   a.diag = h->diag;
   a.passes = h->passes;
