@@ -1,0 +1,97 @@
+"""Randomised parity sweep (`-m gpu`): shapes, kernel families and lane groupings, parameter sets, weights and warm starts drawn
+from a seeded generator, every draw through the C-ABI against the oracle.  The fixed cases of test_gpu_parity.py pin named
+behaviours; this sweep looks for what nobody thought of naming — in particular in the paths added in round 3 (lane sharing in
+the grouped family, two and four wavefronts per sampled solve), whose lane ↔ step maps depend on the shape in many ways."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TIGHT = 1e-9
+
+
+def _compare(got, want, what):
+    same = (got["iters"] == want["iters"]) & (got["status"] == want["status"])
+    assert same.all(), "%s: %d solves took a different accept/reject path" % (what, int((~same).sum()))
+    fin = np.isfinite(want["U"]).all(axis=1)
+    assert np.array_equal(np.isfinite(got["U"]).all(axis=1), fin), what
+    if fin.any():
+        assert np.max(np.abs(got["U"][fin] - want["U"][fin])) <= TIGHT, what
+        assert np.max(np.abs(got["X"][fin] - want["X"][fin])) <= 100 * TIGHT, what
+        assert np.allclose(got["J"][fin], want["J"][fin], rtol=1e-9, atol=1e-9), what
+
+
+def _tweak(p, rng):
+    """A parameter set off the defaults (both bindings' structs carry the same field names)."""
+    p.w_pos = float(rng.uniform(0.3, 1.5)); p.w_vel = float(rng.uniform(1.0, 5.0)); p.w_acc = float(rng.uniform(0.5, 2.0))
+    p.w_yawrate = float(rng.uniform(2.0, 6.0)); p.desired_speed = float(rng.uniform(3.0, 8.0)); p.w_obstacle = float(rng.uniform(0.5, 2.0))
+    p.q2_front = float(rng.uniform(2.0, 3.5)); p.q2_rear = float(rng.uniform(2.0, 3.0)); p.t_safe = float(rng.uniform(0.0, 0.3))
+    p.max_iterations = int(rng.integers(3, 21)); p.tolerance = float(10.0 ** rng.uniform(-5, -2))
+    return p
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_static_scenes(cilqr, oracle, monkeypatch, seed):
+    from cilqr_amd import scenes
+    rng = np.random.default_rng(9100 + seed)
+    N, M, B = int(rng.integers(2, 91)), int(rng.integers(0, 13)), int(rng.integers(1, 301))
+    G = int(rng.choice([0, 1, 2, 4, 8, 16, 32, 64]))
+    if G:
+        monkeypatch.setenv("CILQR_FORCE_G", str(G))
+    p, po = cilqr.default_params(N), oracle.default_params(N)
+    if seed % 2:
+        state = rng.bit_generator.state
+        _tweak(p, rng)
+        rng.bit_generator.state = state
+        _tweak(po, rng)
+    sc = scenes.make_static(B, N, M, p, 9200 + seed)
+    if M and rng.random() < 0.5:
+        sc["obs_weight"] = rng.uniform(0.2, 2.0, (B, M))
+    if rng.random() < 0.5:
+        sc["U"] = sc["U"] + rng.normal(0.0, 0.25, sc["U"].shape)
+    if M and rng.random() < 0.5:  # moving obstacles
+        pose = sc["obs_pose"].reshape(B, M, N, 4).copy()
+        v = rng.uniform(0.0, 6.0, (B, M, 1))
+        pose[..., 2] = v
+        pose[..., 0] += v * np.cos(pose[..., 3]) * p.timestep * np.arange(N)
+        pose[..., 1] += v * np.sin(pose[..., 3]) * p.timestep * np.arange(N)
+        sc["obs_pose"] = pose.reshape(B, M, 4 * N)
+    s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=max(M, 1), device=0)
+    try:
+        got = s.solve_batch(N, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"], sc["obs_weight"])
+    finally:
+        s.close()
+    want = oracle.solve_batch(po, N, M, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"], sc["obs_weight"],
+                              threads=min(16, oracle.max_threads()))
+    _compare(got, want, "seed %d: N=%d M=%d B=%d G=%d" % (seed, N, M, B, G))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_sampled_scenes(cilqr, oracle, monkeypatch, seed):
+    from cilqr_amd import scenes
+    rng = np.random.default_rng(9300 + seed)
+    N, n_dyn, S, B = int(rng.integers(3, 70)), int(rng.integers(1, 9)), int(rng.integers(2, 12)), int(rng.integers(1, 120))
+    W = int(rng.choice([0, 2, 4]))
+    if W:
+        monkeypatch.setenv("CILQR_SPLIT_W", str(W))
+    else:
+        monkeypatch.setenv("CILQR_NO_SPLIT_KERNEL", "1")
+    p, po = cilqr.default_params(N), oracle.default_params(N)
+    st = scenes.make_static(B, N, n_dyn, p, 9400 + seed)
+    pose = st["obs_pose"].reshape(B, n_dyn, N, 4).copy()
+    v = rng.uniform(0.0, 7.0, (B, n_dyn, 1))
+    pose[..., 2] = v
+    pose[..., 0] += v * np.cos(pose[..., 3]) * p.timestep * np.arange(N)
+    pose[..., 1] += v * np.sin(pose[..., 3]) * p.timestep * np.arange(N)
+    if n_dyn > 1:
+        pose[:, 1, :, 3] += 0.02 * np.arange(N)  # one obstacle turns: its samples are derived per entry
+    off = rng.normal(0.0, 1.0, (B, n_dyn, S, 3)) * scenes.POSE_SIGMA
+    nom_pose, nom_dim = pose.reshape(B, n_dyn, 4 * N), st["obs_dim"]
+    mp, md, mw = scenes.materialise_samples(nom_pose, nom_dim, off, N)
+    s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=n_dyn * S, device=0)
+    try:
+        got = s.solve_batch_sampled(N, st["x0"], st["U"], st["poly"], st["xplan_fl"], nom_pose, nom_dim, off, 1.0 / S)
+    finally:
+        s.close()
+    want = oracle.solve_batch(po, N, n_dyn * S, st["x0"], st["U"], st["poly"], st["xplan_fl"], mp, md, mw, threads=min(16, oracle.max_threads()))
+    _compare(got, want, "seed %d: N=%d n_dyn=%d S=%d B=%d W=%d" % (seed, N, n_dyn, S, B, W))
