@@ -12,6 +12,8 @@
 // source cache lines) share an L2.
 // The index arithmetic is fp64 with contraction OFF and IEEE division so that indices are bit-identical to the
 // reference's (an fma here would move cells that sit on a source-cell boundary).
+#include <stdlib.h>
+
 #include "cilqr_internal.h"
 
 namespace cilqr {
@@ -143,17 +145,21 @@ __global__ __launch_bounds__(NTHREADS) void warp_kernel(WarpArgs a, int tiles_i,
 // four consecutive rows i of one column: ONE 16-byte store (and one 16-byte bbox load) per lane and column, a whole KiB per
 // wavefront instruction, the four source cells gathered separately (they are neighbours in the source: same or adjacent
 // lines).  The per-cell index arithmetic is the single-frame kernel's, bit for bit.
-constexpr int VT_I = 256;  // rows per tile = 64 lanes x 4
 constexpr int VT_J = 8;    // columns per tile: wave w handles j = w, w + 4
 
+// ROWS consecutive rows per lane (4 or 8): ROWS / 4 16-byte stores per lane and column; one cell of a run exact, the others by
+// estimate; a cell that lands in the source cell of the one before it (two of four do at 0.1 m against 0.2 m resolution, whatever
+// the rotation) takes its value without another gather.
+template <int ROWS>
 __global__ __launch_bounds__(NTHREADS) void warp_batch_kernel(WarpBatchArgs a, int tiles_i) {
 #pragma clang fp contract(off)
+  constexpr int VT_I = 64 * ROWS;  // rows per tile
   const int frame = blockIdx.y;
   const double* pose = a.poses ? a.poses + 4 * (size_t)frame : a.pose0;  // (wave-uniform; a single frame carries its pose in the arguments)
   const double vx = pose[0], vy = pose[1], sin_t = pose[2], cos_t = pose[3];
   const int ti = blockIdx.x % tiles_i, tj = blockIdx.x / tiles_i;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i0 = ti * VT_I + 4 * lane;
+  const int i0 = ti * VT_I + ROWS * lane;
   const int drows = a.dg.rows, dcols = a.dg.cols;
   const size_t frame_cells = (size_t)drows * dcols;
   float* dst = a.dst + frame * frame_cells;
@@ -161,54 +167,56 @@ __global__ __launch_bounds__(NTHREADS) void warp_batch_kernel(WarpBatchArgs a, i
   const double off_sx = 0.5 * a.sg.len_x, off_sy = 0.5 * a.sg.len_y;
   const double rres = 1.0 / a.sg.res, nrres = -rres;
   const double guard = estimate_guard(a.sg, a.dg, vx, vy, rres);
-  // a lane's four rows: the centre advances by (-res cos, -res sin) from one row to the next
+  // a lane's rows: the centre advances by (-res cos, -res sin) from one row to the next
   const double step_x = -a.dg.res * cos_t, step_y = -a.dg.res * sin_t;
-  double cxc[4], cxs[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const double Cx = (a.dg.pos_x + off_dx) + a.dg.res * (double)(-(i0 + k));
-    cxc[k] = Cx * cos_t;
-    cxs[k] = Cx * sin_t;
-  }
   unsigned long long oob = 0;
-  const bool in_i = i0 < drows;  // drows is a multiple of 4 on this path: a lane's four rows are all inside or all outside
+  const bool in_i = i0 < drows;  // drows is a multiple of ROWS on this path: a lane's rows are all inside or all outside
 #pragma unroll
   for (int jj = 0; jj < VT_J / 4; ++jj) {
     const int j = tj * VT_J + wave + 4 * jj;
     if (j >= dcols || !in_i) break;
     const double Cy = (a.dg.pos_y + off_dy) + a.dg.res * (double)(-j);
     const double cys = Cy * sin_t, cyc = Cy * cos_t;
-    float v[4];
+    float v[ROWS];
     double t0x = 0.0, t0y = 0.0;
+    int psi = -2, psj = -2;  // the source cell of the cell before (-2: none)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < ROWS; ++k) {
       bool ok;
       int si, sj;
       bool have = false;
       if (k > 0) have = cell_estimated(a.sg, t0x + (double)k * step_x, t0y + (double)k * step_y, nrres, guard, ok, si, sj);
       if (!have) {  // the first row of the run, and any cell whose estimate is too close to a source-cell boundary
-        const double x_og = (cxc[k] - cys) + vx;
-        const double y_og = (cxs[k] + cyc) + vy;
+        const double Cx = (a.dg.pos_x + off_dx) + a.dg.res * (double)(-(i0 + k));
+        const double x_og = (Cx * cos_t - cys) + vx;
+        const double y_og = (Cx * sin_t + cyc) + vy;
         double tx_, ty_;
         ok = cell_exact(a.sg, x_og, y_og, off_sx, off_sy, rres, si, sj, tx_, ty_);
         if (k == 0) { t0x = tx_; t0y = ty_; }
       }
-      if (ok) {
-        v[k] = a.src[(size_t)sj * a.sg.rows + si];
-      } else {
+      if (!ok) {
         v[k] = __builtin_nanf("");
         ++oob;
+        psi = -2;
+      } else if (k > 0 && si == psi && sj == psj) {
+        v[k] = v[k - 1];
+      } else {
+        v[k] = a.src[(size_t)sj * a.sg.rows + si];
+        psi = si; psj = sj;
       }
     }
     const size_t lin = (size_t)j * drows + i0;
-    if (a.bbox) {
-      const float4 bb = *reinterpret_cast<const float4*>(a.bbox + lin);
-      if (bb.x > 90.0f) v[0] = bb.x;
-      if (bb.y > 90.0f) v[1] = bb.y;
-      if (bb.z > 90.0f) v[2] = bb.z;
-      if (bb.w > 90.0f) v[3] = bb.w;
+#pragma unroll
+    for (int q = 0; q < ROWS / 4; ++q) {
+      if (a.bbox) {
+        const float4 bb = *reinterpret_cast<const float4*>(a.bbox + lin + 4 * q);
+        if (bb.x > 90.0f) v[4 * q] = bb.x;
+        if (bb.y > 90.0f) v[4 * q + 1] = bb.y;
+        if (bb.z > 90.0f) v[4 * q + 2] = bb.z;
+        if (bb.w > 90.0f) v[4 * q + 3] = bb.w;
+      }
+      *reinterpret_cast<float4*>(dst + lin + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     }
-    *reinterpret_cast<float4*>(dst + lin) = make_float4(v[0], v[1], v[2], v[3]);
   }
   if (a.n_oob) {
     for (int o = 32; o > 0; o >>= 1) oob += __shfl_xor(oob, o, 64);
@@ -221,8 +229,18 @@ __global__ __launch_bounds__(NTHREADS) void warp_batch_kernel(WarpBatchArgs a, i
 hipError_t launch_warp_batch(const WarpBatchArgs& a, int K, hipStream_t stream) {
   if (K <= 0) return hipSuccess;
   if (a.dg.rows % 4 != 0) return hipErrorInvalidValue;  // the caller falls back to per-frame launches
-  const int tiles_i = (a.dg.rows + VT_I - 1) / VT_I, tiles_j = (a.dg.cols + VT_J - 1) / VT_J;
-  hipLaunchKernelGGL(warp_batch_kernel, dim3(tiles_i * tiles_j, K), dim3(NTHREADS), 0, stream, a, tiles_i);
+  const int tiles_j = (a.dg.cols + VT_J - 1) / VT_J;
+  // Four rows per lane.  Eight (CILQR_WARP_ROWS=8: one exact cell in eight) measured slower at every K — 2.83 against 2.41 µs per
+  // frame at K = 16, 10.6 against 8.4 µs for one frame (profiles/r03_warp.txt): half the workgroups, and the arithmetic was not
+  // what bounds the kernel.
+  const int rows8 = getenv("CILQR_WARP_ROWS") ? atoi(getenv("CILQR_WARP_ROWS")) : 4;
+  if (a.dg.rows % 8 == 0 && rows8 == 8) {
+    const int tiles_i = (a.dg.rows + 511) / 512;
+    hipLaunchKernelGGL(warp_batch_kernel<8>, dim3(tiles_i * tiles_j, K), dim3(NTHREADS), 0, stream, a, tiles_i);
+  } else {
+    const int tiles_i = (a.dg.rows + 255) / 256;
+    hipLaunchKernelGGL(warp_batch_kernel<4>, dim3(tiles_i * tiles_j, K), dim3(NTHREADS), 0, stream, a, tiles_i);
+  }
   return hipGetLastError();
 }
 
