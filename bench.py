@@ -829,6 +829,40 @@ def main():
                             "l2_hit_frac": (cnt["TCC_HIT_sum"] / cnt["TCC_REQ_sum"]) if cnt.get("TCC_REQ_sum") else None,
                             "note": "SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES: share of resident-wavefront cycles in which an instruction "
                                     "issued (a lone wavefront issues one per 5.2 ticks, a matrix instruction 16.2)"}
+        if args.workload == "c2" and B <= 1024 and world == 1 and not use_ticks:
+            # A labelled note, never `value`: at one solve per SIMD a launch lasts as long as its slowest solve and most SIMDs idle
+            # through its second half.  Do two INDEPENDENT batches in flight — two handles, two streams, as two
+            # planners sharing the GPU would run — fill that tail?  (A single planner's consecutive ticks depend on each other.)
+            other = cilqr_amd.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M, device=local_rank)
+            Ub, Xb, Jb = U0.clone(), torch.zeros_like(X), torch.zeros_like(J)
+            itb, stb = torch.zeros_like(iters), torch.zeros_like(status)
+            side = [torch.cuda.Stream(), torch.cuda.Stream()]
+            lanes2 = ((solver, U, X, J, iters, status), (other, Ub, Xb, Jb, itb, stb))
+            n2 = max(args.steps // 2, 5)
+
+            def pair_round():
+                for (slv, u, x, j, it_, st_), sd in zip(lanes2, side):
+                    with torch.cuda.stream(sd):
+                        u.copy_(U0)
+                        slv.solve_batch_device(sd.cuda_stream, B, N, M, x0.data_ptr(), u.data_ptr(), poly.data_ptr(), xpl.data_ptr(),
+                                               pose.data_ptr(), dim.data_ptr(), wts.data_ptr() if wts is not None else 0, x.data_ptr(),
+                                               j.data_ptr(), it_.data_ptr(), st_.data_ptr())
+            torch.cuda.synchronize()
+            for _ in range(3):
+                pair_round()
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            for _ in range(n2):
+                pair_round()
+            torch.cuda.synchronize()
+            tp = time.perf_counter() - tp
+            same = bool(torch.equal(U, Ub) and torch.equal(iters, itb))
+            other.close()
+            out["two_batches_in_flight"] = {"value": 2 * n2 * B / tp, "unit": "solves/s", "ms_per_pair": 1e3 * tp / n2, "results_equal": same,
+                                            "note": "NOT the value: two independent batches of %d solves on two handles and streams at once (no "
+                                                    "min-cost selection) — how much of the tail that one launch leaves idle a second, "
+                                                    "independent batch picks up (little: measured 2.45 M against 2.32 M, the launches "
+                                                    "barely overlap; one launch of 2048 solves does: bench.py --batch 2048)" % B}
         # SURVEY §8(d) also asks for the host-buffer entry point (H2D + kernel + D2H); reported, never `value`
         reps = (5 if M <= 16 else 1) if world == 1 else 0
         if reps:
