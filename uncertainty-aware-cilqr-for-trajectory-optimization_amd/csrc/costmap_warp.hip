@@ -12,6 +12,7 @@
 // source cache lines) share an L2.
 // The index arithmetic is fp64 with contraction OFF and IEEE division so that indices are bit-identical to the
 // reference's (an fma here would move cells that sit on a source-cell boundary).
+#include <math.h>
 #include <stdlib.h>
 
 #include "cilqr_internal.h"
@@ -224,11 +225,130 @@ __global__ __launch_bounds__(NTHREADS) void warp_batch_kernel(WarpBatchArgs a, i
   }
 }
 
+// ---- the same frames through LDS: a coalesced 2-D tiled kernel (experiment, see launch_warp_batch) ---------------------------------
+// The gathers of warp_batch_kernel go through the texture path one cache line per distinct source cell and lane.  Here a workgroup owns a compact destination tile — 64 rows × 32 columns, 6.4 m ×
+// 3.2 m at the node's 0.1 m — whose source footprint is a small rotated rectangle: its bounding box in source cells (from the
+// tile's four corner centres, widened by two cells) is loaded ONCE into LDS with coalesced row segments, and every destination
+// cell then reads its source cell from LDS.  Index arithmetic and results are those of the other kernels, bit for bit; a source
+// cell outside the staged box (cannot happen by construction; guarded all the same) is read from global memory.
+constexpr int LT_I = 64, LT_J = 32;  // destination tile: rows × columns; 256 threads = 16 row groups of 4 rows × 16 columns, two columns each
+
+__global__ __launch_bounds__(NTHREADS) void warp_tile_kernel(WarpBatchArgs a, int tiles_i, int lds_cells) {
+#pragma clang fp contract(off)
+  extern __shared__ float tile_src[];
+  const int frame = blockIdx.y;
+  const double* pose = a.poses ? a.poses + 4 * (size_t)frame : a.pose0;
+  const double vx = pose[0], vy = pose[1], sin_t = pose[2], cos_t = pose[3];
+  const int ti = blockIdx.x % tiles_i, tj = blockIdx.x / tiles_i;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int drows = a.dg.rows, dcols = a.dg.cols;
+  const size_t frame_cells = (size_t)drows * dcols;
+  float* dst = a.dst + frame * frame_cells;
+  const double off_dx = 0.5 * a.dg.len_x - 0.5 * a.dg.res, off_dy = 0.5 * a.dg.len_y - 0.5 * a.dg.res;
+  const double off_sx = 0.5 * a.sg.len_x, off_sy = 0.5 * a.sg.len_y;
+  const double rres = 1.0 / a.sg.res, nrres = -rres;
+  const double guard = estimate_guard(a.sg, a.dg, vx, vy, rres);
+  const double step_x = -a.dg.res * cos_t, step_y = -a.dg.res * sin_t;
+
+  // bounding box of the tile's footprint in source cells: the map is affine, so the extremes lie at the corner centres
+  int si_lo, si_hi, sj_lo, sj_hi;
+  {
+    const int ia = ti * LT_I, ib = min(ia + LT_I, drows) - 1, ja = tj * LT_J, jb = min(ja + LT_J, dcols) - 1;
+    double qx_lo = 1e300, qx_hi = -1e300, qy_lo = 1e300, qy_hi = -1e300;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const double Cx = (a.dg.pos_x + off_dx) + a.dg.res * (double)(-((c & 1) ? ib : ia));
+      const double Cy = (a.dg.pos_y + off_dy) + a.dg.res * (double)(-((c & 2) ? jb : ja));
+      const double qx = (((Cx * cos_t - Cy * sin_t) + vx - off_sx) - a.sg.pos_x) * nrres;
+      const double qy = (((Cx * sin_t + Cy * cos_t) + vy - off_sy) - a.sg.pos_y) * nrres;
+      qx_lo = __builtin_fmin(qx_lo, qx); qx_hi = __builtin_fmax(qx_hi, qx);
+      qy_lo = __builtin_fmin(qy_lo, qy); qy_hi = __builtin_fmax(qy_hi, qy);
+    }
+    // (NaN / infinite poses: the comparisons below fail and the box is empty — every cell then takes the global path or is out of range)
+    const bool fin = qx_lo > -2e9 && qx_hi < 2e9 && qy_lo > -2e9 && qy_hi < 2e9;
+    si_lo = fin ? max((int)__builtin_floor(qx_lo) - 2, 0) : 0;
+    si_hi = fin ? min((int)__builtin_floor(qx_hi) + 2, a.sg.rows - 1) : -1;
+    sj_lo = fin ? max((int)__builtin_floor(qy_lo) - 2, 0) : 0;
+    sj_hi = fin ? min((int)__builtin_floor(qy_hi) + 2, a.sg.cols - 1) : -1;
+  }
+  int W = si_hi - si_lo + 1, H = sj_hi - sj_lo + 1;
+  if (W <= 0 || H <= 0 || (long)W * H > lds_cells) { W = 0; H = 0; }  // nothing staged: the guard below sends every read to global memory
+  for (int h = wave; h < H; h += NTHREADS / 64) {
+    const float* row = a.src + (size_t)(sj_lo + h) * a.sg.rows + si_lo;
+    for (int w = lane; w < W; w += 64) tile_src[h * W + w] = row[w];
+  }
+  __syncthreads();
+
+  const int rg = tid & 15, cj = tid >> 4;
+  const int i0 = ti * LT_I + 4 * rg;
+  unsigned long long oob = 0;
+  if (i0 < drows) {  // (drows is a multiple of 4 on this path)
+#pragma unroll
+    for (int jj = 0; jj < LT_J / 16; ++jj) {
+      const int j = tj * LT_J + cj + 16 * jj;
+      if (j >= dcols) break;
+      const double Cy = (a.dg.pos_y + off_dy) + a.dg.res * (double)(-j);
+      const double cys = Cy * sin_t, cyc = Cy * cos_t;
+      float v[4];
+      double t0x = 0.0, t0y = 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        bool ok;
+        int si, sj;
+        bool have = false;
+        if (k > 0) have = cell_estimated(a.sg, t0x + (double)k * step_x, t0y + (double)k * step_y, nrres, guard, ok, si, sj);
+        if (!have) {
+          const double Cx = (a.dg.pos_x + off_dx) + a.dg.res * (double)(-(i0 + k));
+          const double x_og = (Cx * cos_t - cys) + vx;
+          const double y_og = (Cx * sin_t + cyc) + vy;
+          double tx_, ty_;
+          ok = cell_exact(a.sg, x_og, y_og, off_sx, off_sy, rres, si, sj, tx_, ty_);
+          if (k == 0) { t0x = tx_; t0y = ty_; }
+        }
+        if (!ok) {
+          v[k] = __builtin_nanf("");
+          ++oob;
+        } else {
+          const int u = si - si_lo, w = sj - sj_lo;
+          v[k] = ((unsigned)u < (unsigned)W && (unsigned)w < (unsigned)H) ? tile_src[w * W + u] : a.src[(size_t)sj * a.sg.rows + si];
+        }
+      }
+      const size_t lin = (size_t)j * drows + i0;
+      if (a.bbox) {
+        const float4 bb = *reinterpret_cast<const float4*>(a.bbox + lin);
+        if (bb.x > 90.0f) v[0] = bb.x;
+        if (bb.y > 90.0f) v[1] = bb.y;
+        if (bb.z > 90.0f) v[2] = bb.z;
+        if (bb.w > 90.0f) v[3] = bb.w;
+      }
+      *reinterpret_cast<float4*>(dst + lin) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+  if (a.n_oob) {
+    for (int o = 32; o > 0; o >>= 1) oob += __shfl_xor(oob, o, 64);
+    if (lane == 0 && oob) atomicAdd(a.n_oob + frame, oob);
+  }
+}
+
 }  // namespace
 
 hipError_t launch_warp_batch(const WarpBatchArgs& a, int K, hipStream_t stream) {
   if (K <= 0) return hipSuccess;
   if (a.dg.rows % 4 != 0) return hipErrorInvalidValue;  // the caller falls back to per-frame launches
+  // The LDS-tiled kernel is an experiment, OFF unless CILQR_WARP_LDS=1: bit-exact, but slower than the gather kernel below at every
+  // K (profiles/r03_warp.txt: 3.4 against 2.4 µs per frame at K = 16, 2.7 against 1.9 at K = 64) — the texture path's gathers from an
+  // L2-resident patch were not what bounds the kernel, and the staging (box, loads, barrier, four workgroups' worth of LDS) is not free.
+  {
+    const double ratio = a.dg.res / a.sg.res;
+    const double side = ceil(sqrt((double)(LT_I * LT_I + LT_J * LT_J)) * ratio) + 6.0;
+    const char* sw = getenv("CILQR_WARP_LDS");
+    if (sw && atoi(sw) != 0 && side * side * sizeof(float) <= 48.0 * 1024.0) {
+      const int cells = (int)(side * side);
+      const int ti = (a.dg.rows + LT_I - 1) / LT_I, tj = (a.dg.cols + LT_J - 1) / LT_J;
+      hipLaunchKernelGGL(warp_tile_kernel, dim3(ti * tj, K), dim3(NTHREADS), (size_t)cells * sizeof(float), stream, a, ti, cells);
+      return hipGetLastError();
+    }
+  }
   const int tiles_j = (a.dg.cols + VT_J - 1) / VT_J;
   // Four rows per lane.  Eight (CILQR_WARP_ROWS=8: one exact cell in eight) measured slower at every K — 2.83 against 2.41 µs per
   // frame at K = 16, 10.6 against 8.4 µs for one frame (profiles/r03_warp.txt): half the workgroups, and the arithmetic was not
