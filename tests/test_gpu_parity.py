@@ -1851,11 +1851,17 @@ def test_cpp_adapter_uncertainty_map(cilqr, oracle, tmp_path):
     assert np.max(np.abs(w_on["U"] - w_off["U"])) > 1e-3
 
 
-def test_warp_batch_equals_single_frames(cilqr, oracle):
+@pytest.mark.parametrize("variant", ["default", "lds_tiles", "eight_rows"])
+def test_warp_batch_equals_single_frames(cilqr, oracle, monkeypatch, variant):
     """cilqr_warp_costmap_batch_device (K frames per launch, 16-byte stores) against the single-frame kernel and the oracle,
     bit for bit: config-4 shape with out-of-range frames and a bbox layer, a small map whose rows are a multiple of 4 but
-    not of the tile, and a map whose rows are not a multiple of 4 (frame-by-frame fallback)."""
+    not of the tile, and a map whose rows are not a multiple of 4 (frame-by-frame fallback).  Also the two kernels kept as
+    measured-and-dropped experiments: the LDS-tiled one (CILQR_WARP_LDS=1) and eight rows per lane (CILQR_WARP_ROWS=8)."""
     import torch
+    if variant == "lds_tiles":
+        monkeypatch.setenv("CILQR_WARP_LDS", "1")
+    if variant == "eight_rows":
+        monkeypatch.setenv("CILQR_WARP_ROWS", "8")
     from cilqr_amd import scenes
     dev = torch.device("cuda", 0)
     s = cilqr.Solver(cilqr.default_params(), max_batch=1, max_horizon=1, max_obstacles=0, device=0)
