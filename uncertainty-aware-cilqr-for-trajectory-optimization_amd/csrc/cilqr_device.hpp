@@ -262,7 +262,8 @@ __device__ __forceinline__ void forward_controls_scalar(const FwdIn& c, const St
   const double d0 = s.x - c.x, d1 = s.y - c.y, d2 = s.v - c.v, d3 = s.th - c.th;
   const double t0 = fma(c.g[5], d3, fma(c.g[4], d2, fma(c.g[3], d1, c.g[2] * d0)));
   const double t1 = fma(c.g[9], d3, fma(c.g[8], d2, fma(c.g[7], d1, c.g[6] * d0)));
-  u0 = fma(t0 + c.g[0], inv_half_dt, c.u0);
+  // (the old control as the SCALAR addend of a three-operand fma: left to itself hipcc copies it into vector registers for v_fmac)
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(u0) : "v"(t0 + c.g[0]), "v"(inv_half_dt), "s"(c.u0));
   u1 = (t1 + c.g[1]) + c.u1;
 }
 template <bool SCALED = false>

@@ -687,7 +687,7 @@ __device__ __forceinline__ bool forward_smem(const KParams& kp, int N, const dou
   FwdS r;
   FwdIn c;
   f_sload_first(r, recp(0));
-  for (int i = 0; i < N; ++i) {
+  auto step = [&](int i) {
     f_swait(r);
     f_sunpack(c, r);
     double u0, u1;
@@ -703,7 +703,14 @@ __device__ __forceinline__ bool forward_smem(const KParams& kp, int N, const dou
     // the only safe wait with scalar loads in flight — would otherwise pay
     rotate_heading(k, delta, s.s, s.c);
     CILQR_PIN2(s.s, s.c);
+  };
+  // two steps per trip: the rotated (cos, sin) of one step are the inputs of the next in other registers, no copies at the back edge
+  int i = 0;
+  for (; i + 1 < N; i += 2) {
+    step(i);
+    step(i + 1);
   }
+  if (i < N) step(i);
   f_swait(r);  // (the request of the last step: the dump record)
   return max_turn <= MAX_TURN;
 }
