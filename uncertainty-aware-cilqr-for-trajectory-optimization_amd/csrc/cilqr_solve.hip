@@ -1388,8 +1388,18 @@ __global__ __launch_bounds__(2 * WAVE) void cilqr_solve_pair_kernel(SolveArgs a)
 // kernel in the last bits (tolerance against the oracle unchanged), deterministic, independent of the batch around the solve.
 // Horizons up to 64 (one step per lane: wavefront 0 holds its step's record in registers across the barrier).
 // W = wavefronts per solve (2 or 4): wavefront w takes the obstacles w, w + W, …; wavefront 0 adds the others' sums in the order 1, 2, 3.
-template <int W>
+// DIAG: wavefront 0 stamps its phases into a.diag[b] = {prologue, L (its own share + the wait for the others + the combine), R, F,
+// epilogue, #L, #R, total}, as cilqr_solve_kernel does.
+template <int W, bool DIAG>
 __global__ __launch_bounds__(W * WAVE) void cilqr_solve_split_kernel(SolveArgs a) {
+  unsigned long long tk0 = 0, tk = 0, c_pro = 0, c_L = 0, c_R = 0, c_F = 0, n_L = 0, n_R = 0;
+  if (DIAG) tk0 = tk = __builtin_readcyclecounter();
+#define CILQR_STAMP(acc)                                 \
+  if (DIAG) {                                            \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    acc += now_ - tk;                                    \
+    tk = now_;                                           \
+  }
   extern __shared__ __attribute__((aligned(16))) double lds[];
   if ((int)blockIdx.x >= a.B) return;
   const int b = __builtin_amdgcn_readfirstlane(a.order ? a.order[blockIdx.x] : (int)blockIdx.x);
@@ -1466,6 +1476,7 @@ __global__ __launch_bounds__(W * WAVE) void cilqr_solve_split_kernel(SolveArgs a
   }
 
   // ---- wavefront 0 ---------------------------------------------------------------------------------------------------------------
+  CILQR_STAMP(c_pro)
   double J_old = DBL_MAX, lamb = 1.0, J_new = 0.0;
   int iters = 0, status = CILQR_EXIT_MAX_ITER, n_pass = 0;
   bool j_valid = false;
@@ -1502,6 +1513,8 @@ __global__ __launch_bounds__(W * WAVE) void cilqr_solve_split_kernel(SolveArgs a
       J_new = wave_sum_uniform(Jt);
       j_valid = true;
     }
+    CILQR_STAMP(c_L)
+    if (DIAG) ++n_L;
     const bool accept = J_new < J_old;
     bool stop = false;
     if (!accept) {
@@ -1522,7 +1535,9 @@ __global__ __launch_bounds__(W * WAVE) void cilqr_solve_split_kernel(SolveArgs a
         handover = true;
         stop = true;
       } else {
+        CILQR_STAMP(c_R)
         ++n_pass;
+        if (DIAG) ++n_R;
         if (!forward_fast<RECF>(KParams(phase_params()), N, Xa, Ua, rec, Xa, Ua)) {
           handover = true;
           stop = true;
@@ -1537,6 +1552,7 @@ __global__ __launch_bounds__(W * WAVE) void cilqr_solve_split_kernel(SolveArgs a
     }
     if (stop && lane == 0) *reinterpret_cast<volatile int*>(cmd) = CMD_EXIT;
     __syncthreads();  // B
+    CILQR_STAMP(c_F)
     if (stop) break;
   }
 
@@ -1563,6 +1579,13 @@ __global__ __launch_bounds__(W * WAVE) void cilqr_solve_split_kernel(SolveArgs a
     if (ae.passes) ae.passes[b] = n_pass;
     if (ae.hint_passes) ae.hint_passes[b] = n_pass;
   }
+  if (DIAG && lane == 0 && a.diag) {
+    const unsigned long long now_ = __builtin_readcyclecounter();
+    unsigned long long* o = a.diag + (size_t)b * DIAG_SLOTS;
+    o[0] = c_pro; o[1] = c_L; o[2] = c_R; o[3] = c_F; o[4] = now_ - tk; o[5] = n_L; o[6] = n_R; o[7] = now_ - tk0;
+    for (int q = 8; q < DIAG_SLOTS; ++q) o[q] = 0;
+  }
+#undef CILQR_STAMP
 }
 
 __global__ void quu_inverse_kernel(int n, const double* q, const double* lamb, double* out, int general) {
@@ -1691,15 +1714,21 @@ hipError_t launch_solve_wave(const SolveArgs& a, hipStream_t stream) {
   if (a.n_samples > 0) {  // sampled obstacles: offset records in LDS, nominal records in the global workspace
     const size_t extra = solve_sampled_lds_bytes(a.M, a.n_samples);
     if (lds + extra > SOLVE_LDS_MAX) return hipErrorInvalidValue;  // checked by the caller
-    if (a.split >= 2 && a.N <= WAVE && a.M >= a.split && !a.diag && !a.unc.layer && (a.flags & CILQR_FLAG_FAITHFUL_ITERS) == 0) {
+    if (a.split >= 2 && a.N <= WAVE && a.M >= a.split && !a.unc.layer && (a.flags & CILQR_FLAG_FAITHFUL_ITERS) == 0) {
       // a.split wavefronts per solve share phase L (cilqr_solve_split_kernel); the GENERAL kernel of the one-wavefront family behind
       const int W = a.split >= 4 ? 4 : 2;
       const size_t lds_fast = core_lds_bytes(a.N, a.kp.n_samples, true) + extra + ((((size_t)(W - 1) * 5 * a.N + 1) & ~(size_t)1) + 2) * sizeof(double);
       const size_t lds_general = core_lds_bytes(a.N, a.kp.n_samples, false) + extra;
       if (lds_fast <= 64 * 1024 && lds_general <= 64 * 1024) {
-        if (W == 4) hipLaunchKernelGGL((cilqr_solve_split_kernel<4>), dim3(a.B), dim3(4 * WAVE), lds_fast, stream, a);
-        else hipLaunchKernelGGL((cilqr_solve_split_kernel<2>), dim3(a.B), dim3(2 * WAVE), lds_fast, stream, a);
-        hipLaunchKernelGGL((cilqr_solve_kernel<false, 2, true, false>), dim3(a.B), dim3(WAVE), lds_general, stream, a);
+        if (a.diag) {
+          if (W == 4) hipLaunchKernelGGL((cilqr_solve_split_kernel<4, true>), dim3(a.B), dim3(4 * WAVE), lds_fast, stream, a);
+          else hipLaunchKernelGGL((cilqr_solve_split_kernel<2, true>), dim3(a.B), dim3(2 * WAVE), lds_fast, stream, a);
+          hipLaunchKernelGGL((cilqr_solve_kernel<true, 2, true, false>), dim3(a.B), dim3(WAVE), lds_general, stream, a);
+        } else {
+          if (W == 4) hipLaunchKernelGGL((cilqr_solve_split_kernel<4, false>), dim3(a.B), dim3(4 * WAVE), lds_fast, stream, a);
+          else hipLaunchKernelGGL((cilqr_solve_split_kernel<2, false>), dim3(a.B), dim3(2 * WAVE), lds_fast, stream, a);
+          hipLaunchKernelGGL((cilqr_solve_kernel<false, 2, true, false>), dim3(a.B), dim3(WAVE), lds_general, stream, a);
+        }
         return hipGetLastError();
       }
     }
