@@ -498,8 +498,8 @@ int cilqr_solve_batch_sampled_device(cilqr_handle* h, void* stream, int B, int N
   a.fwd = h->d_ws;
   a.pair = 0; a.steal = 0;
   // wavefronts per solve sharing phase L (cilqr_solve_split_kernel): four up to one solve per SIMD, where a shorter pass is all that
-  // counts, two beyond (tools/split_ab.py, profiles/r03_split_kernel.txt: B = 256 0.87 / 1.33 / 2.08 ms with 4 / 2 / 1 wavefronts,
-  // B = 1024 1.45 / 1.54 / 2.15, B = 4096 3.77 / 3.27 / 4.32, B = 8192 6.84 / 5.36 / 7.07)
+  // counts, two beyond (tools/split_ab.py, profiles/r03_split_kernel.txt: B = 256 0.88 / 1.35 / 2.08 ms with 4 / 2 / 1 wavefronts,
+  // B = 1024 1.47 / 1.55 / 2.11, B = 4096 3.86 / 3.27 / 3.97, B = 8192 6.81 / 5.48 / 5.68)
   a.split = pick_split_wavefronts(h, B);
   a.redo = h->d_redo;
   a.diag = h->diag;

@@ -801,8 +801,10 @@ __device__ __forceinline__ bool rollout_fast(const KParams& kp, int N, const dou
 // cover (Q_uu not positive semi-definite or not finite; a heading beyond the in-loop sincos range) stops WITHOUT touching
 // its outputs and sets a.redo[b]; the GENERAL = true kernel, launched right behind on the same stream, redoes exactly
 // those solves from their untouched inputs with the branching passes and returns at once for all others.
+// (second launch bound: without a map the kernel must leave room for TWO wavefronts per SIMD — ≤ 256 vector registers; batches
+// beyond one solve per SIMD depend on it, and the sampled instantiation had crept to 257 + 1 after a refactoring, unnoticed)
 template <bool DIAG, int TAB, bool GENERAL, bool UNC>
-__global__ __launch_bounds__(WAVE) void cilqr_solve_kernel(SolveArgs a) {
+__global__ __launch_bounds__(WAVE, UNC ? 1 : 2) void cilqr_solve_kernel(SolveArgs a) {
   unsigned long long tk0 = 0, tk = 0, c_pro = 0, c_L = 0, c_R = 0, c_F = 0, n_L = 0, n_R = 0;
   unsigned long long sub[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // DIAG: ticks inside phases L (0-4) and R (5-7)
   if (DIAG) tk0 = tk = __builtin_readcyclecounter();
