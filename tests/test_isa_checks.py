@@ -9,6 +9,7 @@ import pytest
 from conftest import PKG, ROOT
 
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+import check_kernel_resources as res  # noqa: E402
 import check_smem_hazard as chk  # noqa: E402
 
 HEAD = "0000000000001000 <kern>:\n"
@@ -44,3 +45,22 @@ def test_built_solve_kernels_have_no_scalar_load_hazard():
     violations, loads = chk.check(chk.disassemble(obj))
     assert loads >= 8, "the scalar-path forward pass is missing from the object"
     assert not violations, violations[:3]
+
+
+def test_register_budget_rule_on_synthetic_notes():
+    two = "_ZN5cilqr12_GLOBAL__N_118cilqr_solve_kernelILb0ELi2ELb0ELb0EEEvNS_9SolveArgsE"
+    unc = "_ZN5cilqr12_GLOBAL__N_118cilqr_solve_kernelILb0ELi1ELb0ELb1EEEvNS_9SolveArgsE"
+    c2 = "_ZN5cilqr12_GLOBAL__N_118cilqr_solve_kernelILb0ELi1ELb0ELb0EEEvNS_9SolveArgsE"
+    ok = dict(vgpr=256, agpr=0, vgpr_spill=0, sgpr_spill=60, scratch=0)
+    assert res.check({two: dict(ok, vgpr_spill=1, scratch=8), unc: dict(ok, vgpr=274, agpr=18), c2: ok}) == []
+    assert len(res.check({two: dict(ok, vgpr=257, agpr=1)})) == 1            # the regression this check exists for
+    assert len(res.check({c2: dict(ok, vgpr_spill=3, scratch=24)})) == 1    # the headline kernel must not spill
+
+
+def test_built_solve_kernels_keep_their_register_budgets():
+    obj = os.path.join(PKG, "build", "cilqr_solve.o")
+    if not os.path.exists(obj):
+        pytest.skip("build/cilqr_solve.o not present (the library was built elsewhere)")
+    notes = res.kernel_notes(obj)
+    assert sum(1 for k in notes if "cilqr_solve_kernel" in k) >= 24
+    assert res.check(notes) == []
