@@ -1393,7 +1393,7 @@ __global__ __launch_bounds__(2 * WAVE) void cilqr_solve_pair_kernel(SolveArgs a)
 // DIAG: wavefront 0 stamps its phases into a.diag[b] = {prologue, L (its own share + the wait for the others + the combine), R, F,
 // epilogue, #L, #R, total}, as cilqr_solve_kernel does.
 template <int W, bool DIAG>
-__global__ __launch_bounds__(W * WAVE) void cilqr_solve_split_kernel(SolveArgs a) {
+__global__ __launch_bounds__(W * WAVE, 2) void cilqr_solve_split_kernel(SolveArgs a) {  // (two wavefronts per SIMD: ≤ 256 vector registers)
   unsigned long long tk0 = 0, tk = 0, c_pro = 0, c_L = 0, c_R = 0, c_F = 0, n_L = 0, n_R = 0;
   if (DIAG) tk0 = tk = __builtin_readcyclecounter();
 #define CILQR_STAMP(acc)                                 \
