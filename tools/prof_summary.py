@@ -30,7 +30,7 @@ def short(name, n=90):
 DOMINANT = {"c2": ["cilqr_solve_kernel<false, 1, false", "cilqr_solve_kernel<false"],
             "c3": ["cilqr_solve_split_kernel", "cilqr_solve_kernel<false, 2, false", "cilqr_solve_kernel<false"],
             "c5": ["cilqr_solve_groups_fast", "cilqr_solve_kernel<false, 0, false"],
-            "warp": ["warp_kernel"], "warp16": ["warp_batch_kernel", "warp_rows4_kernel", "warp"],
+            "warp": ["warp_batch_kernel", "warp_kernel"], "warp16": ["warp_batch_kernel", "warp"],
             "occ": ["layer_to_occ_steps_kernel", "layer_to_occ"]}
 
 

@@ -28,7 +28,7 @@ python3 tools/prof_summary.py "${PROF_TITLE:-r03 — solver configurations 2, 3 
   $OUT/c2_pmc_TCC $OUT/c3_pmc_TCC $OUT/c5_pmc_TCC > $ROOT/gpurun_out/prof_solver_summary.md
 # the record bench.py reads its recorded (not live) figures from; PROF_HEAD = `git rev-parse --short HEAD` of the profiled build
 # (the box has no .git), PROF_ROUND = rNN.  Copy both files into profiles/ afterwards.
-python3 tools/prof_summary.py --json $ROOT/gpurun_out/${PROF_ROUND:-r03}_pmc.json --head "${PROF_HEAD:-unknown}" --from-md $ROOT/gpurun_out/prof_solver_summary.md $ROOT/profiles/r02_wide_rows_summary.md
+python3 tools/prof_summary.py --json $ROOT/gpurun_out/${PROF_ROUND:-r03}_pmc.json --head "${PROF_HEAD:-unknown}" --from-md $ROOT/gpurun_out/prof_solver_summary.md $(ls $ROOT/profiles/r*_wide_rows_summary.md | tail -1)
 # keep only the small files that travel back (csv of stats and counters), not the raw traces
 find $OUT -name "*.db" -delete 2>/dev/null || true
 du -sh $OUT

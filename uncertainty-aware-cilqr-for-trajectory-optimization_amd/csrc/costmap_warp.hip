@@ -151,7 +151,9 @@ constexpr int VT_J = 8;    // columns per tile: wave w handles j = w, w + 4
 // ROWS consecutive rows per lane (4 or 8): ROWS / 4 16-byte stores per lane and column; one cell of a run exact, the others by
 // estimate; a cell that lands in the source cell of the one before it (two of four do at 0.1 m against 0.2 m resolution, whatever
 // the rotation) takes its value without another gather.
-template <int ROWS>
+// REUSE: that reuse — worth 6-8 % where frames are many (K ≥ 4); for ONE frame, which is a latency chain and not work, the
+// comparison in front of every gather costs 1.5 µs of 6 (rocprofv3: 7.7 against 6.2 µs), so single frames run without it.
+template <int ROWS, bool REUSE>
 __global__ __launch_bounds__(NTHREADS) void warp_batch_kernel(WarpBatchArgs a, int tiles_i) {
 #pragma clang fp contract(off)
   constexpr int VT_I = 64 * ROWS;  // rows per tile
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(NTHREADS) void warp_batch_kernel(WarpBatchArgs a, i
         v[k] = __builtin_nanf("");
         ++oob;
         psi = -2;
-      } else if (k > 0 && si == psi && sj == psj) {
+      } else if (REUSE && k > 0 && si == psi && sj == psj) {
         v[k] = v[k - 1];
       } else {
         v[k] = a.src[(size_t)sj * a.sg.rows + si];
@@ -356,10 +358,11 @@ hipError_t launch_warp_batch(const WarpBatchArgs& a, int K, hipStream_t stream) 
   const int rows8 = getenv("CILQR_WARP_ROWS") ? atoi(getenv("CILQR_WARP_ROWS")) : 4;
   if (a.dg.rows % 8 == 0 && rows8 == 8) {
     const int tiles_i = (a.dg.rows + 511) / 512;
-    hipLaunchKernelGGL(warp_batch_kernel<8>, dim3(tiles_i * tiles_j, K), dim3(NTHREADS), 0, stream, a, tiles_i);
+    hipLaunchKernelGGL((warp_batch_kernel<8, true>), dim3(tiles_i * tiles_j, K), dim3(NTHREADS), 0, stream, a, tiles_i);
   } else {
     const int tiles_i = (a.dg.rows + 255) / 256;
-    hipLaunchKernelGGL(warp_batch_kernel<4>, dim3(tiles_i * tiles_j, K), dim3(NTHREADS), 0, stream, a, tiles_i);
+    if (K >= 4) hipLaunchKernelGGL((warp_batch_kernel<4, true>), dim3(tiles_i * tiles_j, K), dim3(NTHREADS), 0, stream, a, tiles_i);
+    else hipLaunchKernelGGL((warp_batch_kernel<4, false>), dim3(tiles_i * tiles_j, K), dim3(NTHREADS), 0, stream, a, tiles_i);
   }
   return hipGetLastError();
 }
