@@ -531,12 +531,26 @@ __device__ __forceinline__ ObsTerms obs_terms(const ObsConsts& k, const ObsEntry
 struct StepSums {  // l_x(0,1), l_xx(00, 01, 11) of one step while its obstacle terms are added
   double lx0, lx1, h00, h01, h11;
 };
+// (the fused multiply-adds are written out: every mapping of phase L — one lane per step, four lanes per step, a second wavefront
+// for the obstacle terms — must round these sums alike, whatever the compiler would contract in its surroundings)
 __device__ __forceinline__ void obs_accumulate(StepSums& a, const ObsTerms& g, double w) {
-  a.lx0 += g.gx * w;
-  a.lx1 += g.gy * w;
-  a.h00 += g.gxx * w;
-  a.h01 += g.gxy * w;
-  a.h11 += g.gyy * w;
+  a.lx0 = __builtin_fma(g.gx, w, a.lx0);
+  a.lx1 = __builtin_fma(g.gy, w, a.lx1);
+  a.h00 = __builtin_fma(g.gxx, w, a.h00);
+  a.h01 = __builtin_fma(g.gxy, w, a.h01);
+  a.h11 = __builtin_fma(g.gyy, w, a.h11);
+}
+// l_x(0,1) and l_xx(00, 01, 11) of a step: the tracking terms (I/Constraints.cpp:163-174) plus the SUM of the obstacle terms — the
+// obstacle terms are added up on their own, from zero, in entry order, and join the tracking terms here in one addition each
+// (round 3; before, they were added to the tracking terms one by one).  So whoever forms the obstacle sums — the step's own lane or
+// a lane of another wavefront (cilqr_solve.hip, cilqr_solve_share_kernel) — the record has the same bits.
+__device__ __forceinline__ void state_terms(const KParams& kp, double dx, double dy, const StepSums& a, double& lx0, double& lx1,
+                                            double& l00, double& l01, double& l11) {
+  lx0 = __builtin_fma(2 * kp.w_pos, dx, a.lx0);
+  lx1 = __builtin_fma(2 * kp.w_pos, dy, a.lx1);
+  l00 = kp.w_pos * 2 + a.h00;
+  l01 = a.h01;
+  l11 = kp.w_pos * 2 + a.h11;
 }
 // Control cost (I/Constraints.cpp:110-131): the arguments of its four barrier exponentials, then l_u, l_uu from their values.
 __device__ __forceinline__ void ctrl_args(const KParams& kp, double u0, double u1, double v, double& a1, double& a2, double& a3, double& a4) {
@@ -666,14 +680,11 @@ __device__ __forceinline__ double lin_step(const KParams& kp, double px, double 
                                            Rec& r) {
   // --- tracking cost (I/Constraints.cpp:163-174)
   const double dx = px - cx, dy = py - cy, dv = v - kp.desired_speed;
-  StepSums a;
-  a.lx0 = (2 * kp.w_pos) * dx;
-  a.lx1 = (2 * kp.w_pos) * dy;
   const double lx2 = (2 * kp.w_vel) * dv;
-  a.h00 = kp.w_pos * 2; a.h01 = 0.0; a.h11 = kp.w_pos * 2;
   const double J = stage_cost(kp, dx, dy, dv, u0, u1);
 
-  // --- obstacles (I/Constraints.cpp:177-187, I/Obstacle.cpp:39-112)
+  // --- obstacles (I/Constraints.cpp:177-187, I/Obstacle.cpp:39-112): summed from zero, joined with the tracking terms below
+  StepSums a{0.0, 0.0, 0.0, 0.0, 0.0};
   obstacle_loop<CULL, PAIRED, LANE_EXACT>(make_obs_consts(kp, px, py, ct, st), M, obs, a);
 
   // --- control cost (I/Constraints.cpp:110-131)
@@ -683,8 +694,8 @@ __device__ __forceinline__ double lin_step(const KParams& kp, double px, double 
   const double e2 = exp_fast(a2);
   const double e3 = exp_fast(a3);
   const double e4 = exp_fast(a4);
-  r.lx0 = a.lx0; r.lx1 = a.lx1; r.lx2 = lx2;
-  r.l00 = a.h00; r.l01 = a.h01; r.l11 = a.h11;
+  state_terms(kp, dx, dy, a, r.lx0, r.lx1, r.l00, r.l01, r.l11);
+  r.lx2 = lx2;
   ctrl_terms(kp, u0, u1, e1, e2, e3, e4, r);
 
   // --- A/B entries

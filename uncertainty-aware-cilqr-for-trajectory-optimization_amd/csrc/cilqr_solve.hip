@@ -1150,12 +1150,9 @@ __device__ __forceinline__ bool linearize_quads(const KParams& kp, int N, int M,
     const double cx = fma(grid.dxs, (double)best, grid.xf), cy = samp[best];
     // tracking cost, as lin_step forms it
     const double dx = px - cx, dy = py - cy, dv = v - kp.desired_speed;
-    StepSums a;
-    a.lx0 = (2 * kp.w_pos) * dx;
-    a.lx1 = (2 * kp.w_pos) * dy;
+    StepSums a{0.0, 0.0, 0.0, 0.0, 0.0};
     Rec c;
     c.lx2 = (2 * kp.w_vel) * dv;
-    a.h00 = kp.w_pos * 2; a.h01 = 0.0; a.h11 = kp.w_pos * 2;
     const double J = stage_cost(kp, dx, dy, dv, u0, u1);
     // obstacles: lane `sub` of the quad evaluates entries sub, sub + 4, …; their terms join the sums in entry order
     const ObsConsts oc = make_obs_consts(kp, px, py, ct, st);
@@ -1180,8 +1177,7 @@ __device__ __forceinline__ bool linearize_quads(const KParams& kp, int N, int M,
     double a1, a2, a3, a4;
     ctrl_args(kp, u0, u1, v, a1, a2, a3, a4);
     const double ee = exp_fast(sub == 0 ? a1 : sub == 1 ? a2 : sub == 2 ? a3 : a4);
-    c.lx0 = a.lx0; c.lx1 = a.lx1;
-    c.l00 = a.h00; c.l01 = a.h01; c.l11 = a.h11;
+    state_terms(kp, dx, dy, a, c.lx0, c.lx1, c.l00, c.l01, c.l11);
     ctrl_terms(kp, u0, u1, quad_bcast<0>(ee), quad_bcast<1>(ee), quad_bcast<2>(ee), quad_bcast<3>(ee), c);
     ab_terms(kp, u0, vn, cn, sn, c);
     if (act && sub == 0) {
