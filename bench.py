@@ -749,6 +749,8 @@ def main():
         # which kernel family the library picks for this shape: asked, not restated (cilqr_solve_family)
         lanes = 64 if sampled else solver.solve_family(B, N, M)
         kernel_name = "cilqr_solve_kernel" if lanes == 64 else "cilqr_solve_groups_fast<%d>" % lanes
+        if not sampled and lanes == 64 and solver.solve_wavefronts(B, N, M) == 2:
+            kernel_name = "cilqr_solve_share_kernel"
         if sampled and solver.solve_sampled_wavefronts(B, N, n_dyn) > 1:
             kernel_name = "cilqr_solve_split_kernel<%d>" % solver.solve_sampled_wavefronts(B, N, n_dyn)
         traffic, traffic_tag = (None, None) if (args.workload == "c3" and args.materialised) else recorded_traffic(args.workload, B)

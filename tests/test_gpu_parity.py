@@ -420,7 +420,9 @@ def _pair_vs_single(cilqr, monkeypatch, sc, N, M, B):
     monkeypatch.setenv("CILQR_PAIR_KERNEL", "1")
     two = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=max(M, 1), device=0)
     monkeypatch.delenv("CILQR_PAIR_KERNEL")
+    monkeypatch.setenv("CILQR_NO_SHARE_KERNEL", "1")  # (the ordinary handle would give small batches a second wavefront of another kind)
     one = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=max(M, 1), device=0)
+    monkeypatch.delenv("CILQR_NO_SHARE_KERNEL")
     try:
         return _gpu_batch(two, sc), _gpu_batch(one, sc)
     finally:
@@ -471,6 +473,80 @@ def test_pair_kernel_weights_warm_starts_and_hand_over(cilqr, oracle, monkeypatc
     keep[[3]] = False
     sub = {k: (v[keep] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in sc.items()}
     _compare({k: v[keep] for k, v in got.items()}, _oracle_batch(oracle, N, sub), TIGHT, "two wavefronts, weights and warm starts")
+
+
+def _share_vs_single(cilqr, monkeypatch, sc, N, M, B):
+    """The same batch on an ordinary handle (cilqr_solve_share_kernel where it applies) and on one created with CILQR_NO_SHARE_KERNEL."""
+    p = cilqr.default_params(N)
+    two = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=max(M, 1), device=0)
+    monkeypatch.setenv("CILQR_NO_SHARE_KERNEL", "1")
+    one = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=max(M, 1), device=0)
+    monkeypatch.delenv("CILQR_NO_SHARE_KERNEL")
+    try:
+        return _gpu_batch(two, sc), _gpu_batch(one, sc), two.solve_wavefronts(B, N, M), one.solve_wavefronts(B, N, M)
+    finally:
+        two.close()
+        one.close()
+
+
+def _same_bits(got, ref, what):
+    for k in ("U", "X", "J", "iters", "status"):
+        assert np.array_equal(got[k], ref[k], equal_nan=(k in ("U", "X", "J"))), "%s: %s differs" % (what, k)
+
+
+@pytest.mark.parametrize("N,M,B", [(50, 4, 1024), (50, 4, 2048), (30, 2, 200), (2, 1, 9), (1, 1, 3), (3, 0, 5), (17, 5, 64), (63, 4, 96), (33, 9, 70)])
+def test_share_kernel_changes_no_bit(cilqr, oracle, monkeypatch, N, M, B):
+    """Up to two solves per SIMD a static-obstacle solve runs as a workgroup of two wavefronts that work on phase L at the same time
+    (cilqr_solve_share_kernel: closest samples, tracking terms, control barrier on one; cos / sin, obstacle sums, Jacobians on the
+    other).  The statements are lin_step's, the obstacle terms are summed from zero in every kernel: U, X, J, iterations and exit
+    reasons must be BIT-IDENTICAL to the one-wavefront kernel's — config 2 in full, two solves per SIMD, and ragged shapes
+    (N = 1, 2, 63; no obstacles; more obstacles than fit a round number) — and agree with the oracle."""
+    from cilqr_amd import scenes
+    p = cilqr.default_params(N)
+    sc = scenes.make_static(B, N, M, p, 7300 + N)
+    got, ref, w2, w1 = _share_vs_single(cilqr, monkeypatch, sc, N, M, B)
+    assert (w2, w1) == (2, 1)
+    _same_bits(got, ref, "two wavefronts sharing phase L against one")
+    idx = np.arange(min(B, 128))
+    sub = {k: (v[idx] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in sc.items()}
+    _compare({k: v[idx] for k, v in got.items()}, _oracle_batch(oracle, N, sub), TIGHT, "two wavefronts sharing phase L")
+
+
+def test_share_kernel_weights_warm_starts_and_hand_over(cilqr, oracle, monkeypatch):
+    """The shared-phase-L kernel with per-obstacle weights, warm-started (random) controls, a moving obstacle, and solves that it hands
+    to the GENERAL kernel (a NaN start, a heading beyond the in-loop sincos range, a turn of more than 1/4 rad per step): the bits of
+    the one-wavefront kernel, NaNs included, and the oracle's results where it has finite ones.  Where the kernel does not apply
+    (N = 64: one state per lane no longer fits; a batch beyond two solves per SIMD) the library says so and runs one wavefront."""
+    from cilqr_amd import scenes
+    N, M, B = 50, 6, 160
+    p = cilqr.default_params(N)
+    sc = scenes.make_static(B, N, M, p, 7377)
+    rng = np.random.default_rng(7377)
+    sc["obs_weight"] = rng.uniform(0.2, 2.0, (B, M))
+    sc["U"] = sc["U"] + rng.normal(0.0, 0.3, sc["U"].shape)
+    pose = sc["obs_pose"].reshape(B, M, N, 4).copy()
+    pose[:, 0, :, 2] = 3.0  # a moving obstacle: speed inflates its ellipse (I/Obstacle.cpp:42-43)
+    pose[:, 0, :, 0] += 0.3 * np.arange(N)
+    sc["obs_pose"] = pose.reshape(B, M, 4 * N)
+    sc["x0"][3, 1] = np.nan
+    sc["x0"][5, 3] = 2.0e6
+    sc["x0"][7, 2] = 25.0
+    sc["U"][7, 1::2] = 5.0  # full lock at 25 m/s: more than 1/4 rad per step
+    got, ref, w2, w1 = _share_vs_single(cilqr, monkeypatch, sc, N, M, B)
+    assert (w2, w1) == (2, 1)
+    _same_bits(got, ref, "shared phase L, weights and warm starts")
+    keep = np.ones(B, bool)
+    keep[[3]] = False
+    sub = {k: (v[keep] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in sc.items()}
+    _compare({k: v[keep] for k, v in got.items()}, _oracle_batch(oracle, N, sub), TIGHT, "shared phase L, weights and warm starts")
+    s = cilqr.Solver(cilqr.default_params(64), max_batch=8192, max_horizon=64, max_obstacles=4, device=0)
+    try:
+        simds = 1024  # MI355X: 256 CUs × 4
+        assert s.solve_wavefronts(64, 64, 4) == 1 and s.solve_wavefronts(64, 63, 4) == 2
+        assert s.solve_wavefronts(2 * simds, 50, 4) == 2 and s.solve_wavefronts(2 * simds + 1, 50, 4) == 1
+        assert s.solve_wavefronts(64, 50, 40) == 1  # (the table of 40 obstacles × 50 steps does not fit the LDS share of a solve)
+    finally:
+        s.close()
 
 
 @pytest.mark.parametrize("G,B,N,M", [(8, 520, 80, 16), (1, 300, 30, 2), (4, 333, 50, 4), (16, 90, 50, 5), (32, 40, 64, 3), (2, 257, 20, 0)])

@@ -42,16 +42,17 @@ def check(notes):
     for name, r in sorted(notes.items()):
         m = re.search(r"cilqr_solve_kernelILb(\d)ELi(\d)ELb(\d)ELb(\d)E", name)
         split = re.search(r"cilqr_solve_split_kernelILi(\d)ELb(\d)E", name)
+        share = re.search(r"cilqr_solve_share_kernelILb(\d)E", name)
         if m:
             diag, tab, general, unc = (int(v) for v in m.groups())
             if not unc and r["vgpr"] + r["agpr"] > 256:
                 bad.append((name, r, "more than 256 vector registers: one wavefront per SIMD only"))
             if not diag and not general and not unc and tab != 2 and r["vgpr_spill"]:
                 bad.append((name, r, "a production instantiation spills vector registers"))
-        elif split:
+        elif split or share:
             if r["vgpr"] + r["agpr"] > 256:
                 bad.append((name, r, "more than 256 vector registers: the workgroups of a CU halve"))
-            if not int(split.group(2)) and r["vgpr_spill"]:
+            if not int((split or share).group(split.lastindex if split else 1)) and r["vgpr_spill"]:
                 bad.append((name, r, "a production instantiation spills vector registers"))
     return bad
 

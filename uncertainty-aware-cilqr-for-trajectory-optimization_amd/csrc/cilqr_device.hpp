@@ -376,8 +376,9 @@ __device__ __forceinline__ int closest_sample(int S, const SampleGrid& g, double
 // ---- cost linearisation of one step ----------------------------------------------------------------------------------
 // Stage cost of Constraints::get_J (I/Constraints.cpp:534-561) for one step.
 __device__ __forceinline__ double stage_cost(const KParams& kp, double dx, double dy, double dv, double u0, double u1) {
-  const double xc = (dx * kp.w_pos) * dx + (dy * kp.w_pos) * dy + (dv * kp.w_vel) * dv;
-  const double uc = (u0 * kp.w_acc) * u0 + (u1 * kp.w_yawrate) * u1;
+  // (fused multiply-adds written out: the same bits wherever a kernel forms it)
+  const double xc = __builtin_fma(dv * kp.w_vel, dv, __builtin_fma(dy * kp.w_pos, dy, (dx * kp.w_pos) * dx));
+  const double uc = __builtin_fma(u1 * kp.w_yawrate, u1, (u0 * kp.w_acc) * u0);
   return xc + uc;
 }
 

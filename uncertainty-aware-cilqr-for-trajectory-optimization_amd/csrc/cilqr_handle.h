@@ -77,6 +77,8 @@ struct cilqr_handle {
   int steal_off;       // environment CILQR_NO_LANE_SHARING at create: the grouped family without phase L's lane sharing (A/B, bit-equality test)
   int split_w;         // 0 = automatic; else 2 or 4 (test hook: environment CILQR_SPLIT_W at create)
   int split_off;       // environment CILQR_NO_SPLIT_KERNEL at create: sampled obstacles on one wavefront per solve (A/B, tests)
+  int share_off;       // environment CILQR_NO_SHARE_KERNEL at create: static obstacles on one wavefront per solve at every batch size (A/B, tests)
+  int share_max;       // largest batch on the shared-phase-L kernel (cilqr_solve_share_kernel): the SIMD count; CILQR_SHARE_MAX_B overrides
   int pair_on;         // environment CILQR_PAIR_KERNEL at create: the two-wavefront kernel for batches up to one solve per SIMD
                        // (a measured negative result, DESIGN.md §5: kept for the A/B of tools/pair_ab.py and its tests, off by default)
   int force_g;       // 0 = automatic; else 1,2,4,8,16,32 or 64 (test hook: environment CILQR_FORCE_G at create)

@@ -66,8 +66,9 @@ struct SolveArgs {
   int32_t* hint_passes;  // null, or [B]: passes of each solve of THIS call, from which the next call's order is built
   int32_t B, N, M;
   uint32_t flags;
-  // 1: the batch has at most one solve per SIMD — the launcher may give every solve a second wavefront (cilqr_solve.hip,
-  // cilqr_solve_pair_kernel: the next linearisation runs behind the forward pass instead of after it)
+  // The batch has at most one solve per SIMD — the launcher may give every solve a second wavefront (cilqr_solve.hip).
+  // 1: cilqr_solve_pair_kernel (the next linearisation runs behind the forward pass instead of after it; an experiment);
+  // 2: cilqr_solve_share_kernel (both wavefronts work on phase L at the same time; the default)
   int32_t pair;
   // grouped family: 1 = in phase L the lanes of a wavefront's finished solves take steps of the unfinished ones (cilqr_solve_groups.hip)
   int32_t steal;
@@ -83,6 +84,8 @@ hipError_t launch_solve_wave(const SolveArgs& a, hipStream_t stream);
 hipError_t launch_schedule_order(const int32_t* passes, int B, int32_t* order, hipStream_t stream);  // passes descending
 size_t solve_lds_bytes(int N, int n_samples);
 constexpr size_t SOLVE_LDS_MAX = 160 * 1024;  // LDS of one CU: the horizon bound of the wavefront family
+bool solve_table_in_lds(int N, int M, int n_samples);   // static obstacles: the [M][N] entry table lies in LDS (else in the workspace)
+bool solve_share_applies(int N, int M, int n_samples);  // … and the shape can take cilqr_solve_share_kernel (two wavefronts share phase L)
 size_t solve_sampled_lds_bytes(int n_obs, int n_samples);   // additional LDS of the sampled-obstacle mode
 size_t solve_sampled_tab_doubles(int n_obs, int N);         // its workspace need per solve (in obs_tab)
 // G lanes per solve (G in {1,2,4,8,16,32}), workspace `ws` of solve_groups_ws_doubles(B, N) doubles (cilqr_solve_groups.hip).

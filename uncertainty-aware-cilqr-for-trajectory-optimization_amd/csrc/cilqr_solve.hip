@@ -1586,6 +1586,257 @@ __global__ __launch_bounds__(W * WAVE, 2) void cilqr_solve_split_kernel(SolveArg
 #undef CILQR_STAMP
 }
 
+// ==== Static obstacles, two wavefronts per solve that share phase L (BASELINE config 2's shape, up to one solve per SIMD) ===========
+// A batch of at most one solve per SIMD ends when its LONGEST solve does (config 2: 13 of 1024 solves run all 20 passes, the mean
+// solve 7.8), so what counts is the length of one pass — R + F + L = 18.6 k + 17.8 k + 8.3 k ticks at N = 50, M = 4 — and R and F
+// are serial chains at the issue rate of a lone wavefront.  Phase L is not one chain: the closest-sample search with the tracking
+// terms (≈ 3.1 k ticks per lane) is independent of the obstacle, control-barrier and Jacobian terms (≈ 3.4 k), which need the
+// headings' cos / sin but not the closest sample.  Here a solve is a workgroup of two wavefronts, lanes = timesteps in both:
+//   wavefront 0 ("main"): rollout, R, F as in cilqr_solve_kernel; of phase L the forward-pass rows, the closest-sample search, the
+//                         tracking terms, J and the control barrier; then, behind barrier A, l_x / l_xx = tracking terms + the
+//                         other wavefront's sums;
+//   wavefront 1 ("aux"):  cos / sin of every heading (one state per lane; a step's next heading comes from the lane above), the
+//                         obstacle terms summed from zero into `part`, the Jacobians' record slots straight into the records;
+//                         then it sleeps at barrier B through R and F.
+// Unlike cilqr_solve_pair_kernel (above: the aux wavefront working BEHIND the forward pass, measured slower) nothing is pipelined:
+// both wavefronts work on phase L at the same time and only then, the aux wavefront issues nothing while main runs R and F, and the
+// two meet at two barriers per pass.  While every SIMD still holds a main wavefront the aux wavefronts take issue slots from the
+// main wavefronts of OTHER solves (work-conserving: no gain, no loss to speak of); once the short solves have ended — the larger
+// part of the launch — the long ones have their SIMDs' partners to themselves and a pass is ≈ 4.5 k ticks shorter.
+// Bits: the statements are lin_step's, piece by piece (cilqr_device.hpp: obstacle sums from zero, state_terms), so a record does
+// not depend on which wavefront formed which slot — results are bit-identical to cilqr_solve_kernel's (tests/test_gpu_parity.py,
+// test_share_kernel_changes_no_bit).  Horizons up to 63 (one state per lane), obstacle table in LDS, no map, early-exit mode.
+// DIAG: a.diag[b] = {prologue, L (main's share + the wait at barrier A + the combine), R, F, epilogue, #L, #R, total, aux: busy
+// ticks, aux: calls, main: ticks waiting at barrier A, 0…}.
+template <bool DIAG>
+__global__ __launch_bounds__(2 * WAVE, 2) void cilqr_solve_share_kernel(SolveArgs a) {  // (two wavefronts per SIMD: ≤ 256 vector registers)
+  unsigned long long tk0 = 0, tk = 0, c_pro = 0, c_L = 0, c_R = 0, c_F = 0, n_L = 0, n_R = 0, c_wait = 0;
+  if (DIAG) tk0 = tk = __builtin_readcyclecounter();
+#define CILQR_STAMP(acc)                                 \
+  if (DIAG) {                                            \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    acc += now_ - tk;                                    \
+    tk = now_;                                           \
+  }
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  if ((int)blockIdx.x >= a.B) return;
+  const int b = __builtin_amdgcn_readfirstlane(a.order ? a.order[blockIdx.x] : (int)blockIdx.x);
+  if (b >= a.B) return;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const KParams kp = a.kp;
+  const int N = a.N, M = a.M, S = kp.n_samples;
+  double* samp = lds;  // the compact layout of cilqr_solve_kernel, then `part` and the command word
+  double* Xa = samp + ((S + 1) & ~1);
+  double* Ua = Xa + (N + 1) * XR;
+  double* rec = Ua + 2 * N;
+  double* cst = rec + N * RECF;
+  double* tab = cst + RCST;
+  double* part = tab + (size_t)M * TABF * N;  // [N][5]: the aux wavefront's sums of a step's obstacle terms
+  double* ctl = part + ((5 * N + 1) & ~1);
+  int* const cmd = reinterpret_cast<int*>(ctl);
+  double* fwd = a.fwd + (size_t)b * (N + 1) * FREC;
+
+  // ---- prologue, both wavefronts -----------------------------------------------------------------------------------------------
+  SampleGrid grid;
+  make_sample_grid(grid, a.xplan_fl[2 * b], a.xplan_fl[2 * b + 1], S);
+  {
+    const double* pc = a.poly + (size_t)b * CILQR_POLY_COEFFS;
+    for (int s = tid; s < S; s += 2 * WAVE) {
+      double xs;
+      sample_xy(grid, pc, s, xs, samp[s]);
+    }
+  }
+  const double* Ug = a.U + (size_t)b * 2 * N;
+  for (int i = tid; i < 2 * N; i += 2 * WAVE) Ua[i] = Ug[i];
+  if (tid < 16 && (tid & 7) < 5) cst[(tid & 7) + (tid >> 3) * RECF] = (tid & 7) == 0 ? 0.0 : (tid & 7) == 1 ? 1.0 : (tid & 7) == 2 ? kp.dt : (tid & 7) == 3 ? kp.w_vel * 2 : 2.0;
+  if (tid == 0) cmd[0] = 0;
+  for (int i = tid; i < M * N; i += 2 * WAVE) {  // obstacle table, I/Obstacle.cpp:41-62 (entry i = m·N + t, as the inputs lie)
+    const ObsEntry e = make_obs_entry(kp, a.obs_pose + ((size_t)b * M * N + i) * 4, a.obs_dim + ((size_t)b * M * N + i) * 2);
+    double* o = tab + (size_t)i * TABF;
+    o[0] = e.ox; o[1] = e.oy; o[2] = e.co; o[3] = e.so; o[4] = e.ia2; o[5] = e.ib2;
+  }
+  const double* wts = a.obs_weight ? a.obs_weight + (size_t)b * M : nullptr;
+  __syncthreads();
+  bool handover = false;
+  if (wave == 0) {
+    {  // largest step between adjacent path samples in y: closest_sample's second window (cilqr_device.hpp)
+      double m = 0.0;
+      for (int q = lane; q + 1 < S; q += WAVE) {
+        const double d = fabs(samp[q + 1] - samp[q]);
+        m = fmax(m, d == d ? d : __builtin_huge_val());
+      }
+      grid.dmax = wave_max_uniform(m);
+    }
+    handover = !rollout_fast(kp, N, a.x0 + (size_t)b * 4, Ua, Xa);  // nominal rollout, I/iLQR.cpp:51-62
+    if (handover && lane == 0) *reinterpret_cast<volatile int*>(cmd) = CMD_EXIT;
+  }
+  __syncthreads();  // the trajectory is in LDS
+
+  const int t = lane;
+  const bool act = t < N;
+  if (wave != 0) {
+    // ---- the aux wavefront: cos / sin, obstacle sums, control barrier, Jacobians — pass after pass -------------------------------------
+    unsigned long long busy = 0, calls = 0;
+    for (;;) {
+      if (*reinterpret_cast<volatile int*>(cmd) == CMD_EXIT) break;
+      unsigned long long t0 = 0;
+      if (DIAG) t0 = __builtin_readcyclecounter();
+      const KParams kpl = phase_params();
+      double sA = 0.0, cA = 1.0;
+      if (lane <= N) sincos_loop(Xa[lane * XR + 3], sA, cA);  // (headings within sincos_loop's range: rollout_fast, MAX_TURN)
+      const double cn = __shfl_down(cA, 1, WAVE), sn = __shfl_down(sA, 1, WAVE);
+      if (act) {
+        const double* xr = Xa + t * XR;
+        const double u0 = Ua[2 * t];
+        StepSums s5{0.0, 0.0, 0.0, 0.0, 0.0};
+        obstacle_loop<true, false, true>(make_obs_consts(kpl, xr[0], xr[1], cA, sA), M, TabSource<false>{tab, wts, N, kpl.w_obstacle}.at(t), s5);
+        double* q = part + (size_t)t * 5;
+        q[0] = s5.lx0; q[1] = s5.lx1; q[2] = s5.h00; q[3] = s5.h01; q[4] = s5.h11;
+        Rec c;
+        ab_terms(kpl, u0, Xa[(t + 1) * XR + 2], cn, sn, c);
+        double* r = rec + t * RECF;
+        r[10] = c.al; r[11] = c.be; r[12] = c.ga; r[13] = c.de;
+      }
+      if (DIAG) { busy += stamp_after(cn) - t0; ++calls; }
+      __syncthreads();  // A: sums and record slots are in LDS
+      __syncthreads();  // B: main has decided, and, going on, has written the next trajectory
+    }
+    if (DIAG && lane == 0 && a.diag) {
+      unsigned long long* o = a.diag + (size_t)b * DIAG_SLOTS;
+      o[8] = busy; o[9] = calls;
+    }
+    return;
+  }
+
+  // ---- the main wavefront ----------------------------------------------------------------------------------------------------------
+  CILQR_STAMP(c_pro)
+  double J_old = DBL_MAX, lamb = 1.0, J_new = 0.0;
+  int iters = 0, status = CILQR_EXIT_MAX_ITER, n_pass = 0;
+  bool j_valid = false;
+  const int max_it = kp.max_iterations;
+  for (int it = 0; it < max_it && !handover; ++it) {
+    ++iters;
+    {  // phase L: forward-pass rows, closest sample, tracking terms, J; then the aux wavefront's sums on top
+      const KParams kpl = phase_params();
+      double dx = 0.0, dy = 0.0, lx2 = 0.0, Jt = 0.0;
+      if (act) {
+        const double* xr = Xa + t * XR;
+        const double px = xr[0], py = xr[1], v = xr[2];
+        const double u0 = Ua[2 * t], u1 = Ua[2 * t + 1];
+        double2* q = reinterpret_cast<double2*>(fwd + t * FREC + 10);  // the forward pass reads the old state and control through the scalar path
+        q[0] = make_double2(px, py);
+        q[1] = make_double2(v, xr[3]);
+        q[2] = make_double2(u0, u1);
+        const int cs = closest_sample(S, grid, px, py, LdsSamples{samp, grid.xf, grid.dxs});
+        dx = px - fma(grid.dxs, (double)cs, grid.xf);
+        dy = py - samp[cs];
+        const double dv = v - kpl.desired_speed;
+        lx2 = (2 * kpl.w_vel) * dv;
+        Jt = stage_cost(kpl, dx, dy, dv, u0, u1);
+        Rec c;  // control barrier (I/Constraints.cpp:110-131)
+        double a1, a2, a3, a4;
+        ctrl_args(kpl, u0, u1, v, a1, a2, a3, a4);
+        const double e1 = exp_fast(a1);
+        const double e2 = exp_fast(a2);
+        const double e3 = exp_fast(a3);
+        const double e4 = exp_fast(a4);
+        ctrl_terms(kpl, u0, u1, e1, e2, e3, e4, c);
+        double* r = rec + t * RECF;
+        const double ih = 2.0 / kpl.dt;  // production records: acceleration in units of (dt/2)·u0 (riccati_mfma)
+        r[6] = c.lu0 * ih; r[7] = c.lu1; r[8] = c.luu0 * (ih * ih); r[9] = c.luu1;
+      }
+      J_new = wave_sum_uniform(Jt);
+      unsigned long long w0 = 0;
+      if (DIAG) w0 = stamp_after(J_new);
+      __syncthreads();  // A
+      if (DIAG) c_wait += __builtin_readcyclecounter() - w0;
+      if (act) {
+        const double* q = part + (size_t)t * 5;
+        const StepSums s5{q[0], q[1], q[2], q[3], q[4]};
+        double* r = rec + t * RECF;
+        double lx0, lx1, l00, l01, l11;
+        state_terms(kpl, dx, dy, s5, lx0, lx1, l00, l01, l11);
+        r[0] = lx0; r[1] = lx1; r[2] = lx2; r[3] = l00; r[4] = l01; r[5] = l11;
+      }
+      j_valid = true;
+    }
+    CILQR_STAMP(c_L)
+    if (DIAG) ++n_L;
+    const bool accept = J_new < J_old;
+    bool stop = false;
+    if (!accept) {
+      if (J_new != J_new) {
+        status = CILQR_EXIT_NUMERIC;
+      } else {
+        for (;;) {
+          lamb = lamb * kp.lamb_factor;
+          if (lamb > kp.lamb_max) { status = CILQR_EXIT_LAMBDA_MAX; break; }
+          if (++it >= max_it) { status = CILQR_EXIT_MAX_ITER; break; }
+          ++iters;
+        }
+      }
+      stop = true;
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wavefront's record slots are in LDS (the aux wavefront's: barrier A)
+      if (!riccati_mfma<true, false>(N, rec, rec, fwd, cst, 2.0 / kp.dt, lamb, nullptr)) {
+        handover = true;
+        stop = true;
+      } else {
+        CILQR_STAMP(c_R)
+        ++n_pass;
+        if (DIAG) ++n_R;
+        if (!forward_smem(KParams(phase_params()), N, Xa, fwd, Xa, Ua)) {
+          handover = true;
+          stop = true;
+        } else {
+          j_valid = false;
+          lamb = lamb / kp.lamb_factor;
+          if (fabs(J_new - J_old) < kp.tolerance) { status = CILQR_EXIT_TOLERANCE; stop = true; }
+          J_old = J_new;
+          if (it + 1 >= max_it) stop = true;
+        }
+      }
+    }
+    if (stop && lane == 0) *reinterpret_cast<volatile int*>(cmd) = CMD_EXIT;
+    __syncthreads();  // B
+    CILQR_STAMP(c_F)
+    if (stop) break;
+  }
+
+  int32_t* const hint = phase_args().hint_passes;
+  if (lane == 0) {
+    phase_args().redo[b] = handover ? 1 : 0;
+    if (handover && hint) hint[b] = 63;
+  }
+  if (handover) return;  // outputs (and the in/out U) untouched: the GENERAL kernel starts from the same inputs
+
+  // ---- epilogue: X_result / U_result (:243-244) ------------------------------------------------------------------------------
+  const SolveArgs ae = phase_args();
+  double* Uo = ae.U + (size_t)b * 2 * N;
+  for (int i = lane; i < 2 * N; i += WAVE) Uo[i] = Ua[i];
+  double* Xg = ae.X_out + (size_t)b * 4 * (N + 1);
+  for (int i = lane; i < 4 * (N + 1); i += WAVE) Xg[i] = Xa[(i >> 2) * XR + (i & 3)];
+  if (ae.J_out) {
+    if (!j_valid) J_new = wave_sum_uniform(cost_only(ae.kp, N, lane, samp, S, grid, Xa, Ua));
+    if (lane == 0) ae.J_out[b] = J_new;
+  }
+  if (lane == 0) {
+    if (ae.iters_out) ae.iters_out[b] = iters;
+    if (ae.status_out) ae.status_out[b] = status;
+    if (ae.passes) ae.passes[b] = n_pass;
+    if (ae.hint_passes) ae.hint_passes[b] = n_pass;
+  }
+  if (DIAG && lane == 0 && a.diag) {
+    const unsigned long long now_ = __builtin_readcyclecounter();
+    unsigned long long* o = a.diag + (size_t)b * DIAG_SLOTS;
+    o[0] = c_pro; o[1] = c_L; o[2] = c_R; o[3] = c_F; o[4] = now_ - tk; o[5] = n_L; o[6] = n_R; o[7] = now_ - tk0;
+    o[10] = c_wait;
+    for (int q = 11; q < DIAG_SLOTS; ++q) o[q] = 0;
+  }
+#undef CILQR_STAMP
+}
+
 __global__ void quu_inverse_kernel(int n, const double* q, const double* lamb, double* out, int general) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -1648,6 +1899,15 @@ hipError_t launch_two_wavefronts(const SolveArgs& a, size_t tab_bytes, hipStream
   hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, 1, true, false>), dim3(a.B), dim3(WAVE), lds_general, stream, a);
   return hipGetLastError();
 }
+// The shared-phase-L kernel (table in LDS, no map, early exit, N ≤ 63) with the GENERAL kernel of the one-wavefront family behind it.
+template <bool DIAG>
+hipError_t launch_shared_L(const SolveArgs& a, size_t tab_bytes, hipStream_t stream) {
+  const size_t lds_fast = core_lds_bytes(a.N, a.kp.n_samples, true) + tab_bytes + ((((size_t)5 * a.N + 1) & ~(size_t)1) + 2) * sizeof(double);
+  const size_t lds_general = core_lds_bytes(a.N, a.kp.n_samples, false) + tab_bytes;
+  hipLaunchKernelGGL((cilqr_solve_share_kernel<DIAG>), dim3(a.B), dim3(2 * WAVE), lds_fast, stream, a);
+  hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, 1, true, false>), dim3(a.B), dim3(WAVE), lds_general, stream, a);
+  return hipGetLastError();
+}
 template <bool DIAG, int TAB>
 hipError_t launch_pair(const SolveArgs& a, size_t extra, hipStream_t stream) {
   return a.unc.layer ? launch_pair_unc<DIAG, TAB, true>(a, extra, stream) : launch_pair_unc<DIAG, TAB, false>(a, extra, stream);
@@ -1656,6 +1916,10 @@ hipError_t launch_pair(const SolveArgs& a, size_t extra, hipStream_t stream) {
 }  // namespace
 
 size_t solve_lds_bytes(int N, int n_samples) { return core_lds_bytes(N, n_samples, false); }  // the larger of the two layouts
+// Static obstacles: the table stays in LDS while a workgroup stays within 32 KiB (≥ 5 solves resident per CU of 160 KiB).  (M = 0: an empty table fits)
+bool solve_table_in_lds(int N, int M, int n_samples) { return solve_lds_bytes(N, n_samples) + (size_t)M * TABF * N * sizeof(double) <= 32 * 1024; }
+// … and whether a solve of this shape can take the shared-phase-L kernel (cilqr_solve_share_kernel): table in LDS, one state per lane
+bool solve_share_applies(int N, int M, int n_samples) { return N < WAVE && solve_table_in_lds(N, M, n_samples); }
 
 size_t solve_sampled_lds_bytes(int n_obs, int n_samples) {
   return ((size_t)n_obs * n_samples * OFFF + (size_t)2 * n_obs) * sizeof(double);  // offset records + rmax + constant-shape flags
@@ -1706,9 +1970,8 @@ hipError_t launch_quu_inverse(int n, const double* q, const double* lamb, double
 hipError_t launch_solve_wave(const SolveArgs& a, hipStream_t stream) {
   if (a.B <= 0) return hipSuccess;
   const size_t lds = solve_lds_bytes(a.N, a.kp.n_samples);  // the larger layout: limits and the table decision hold for both kernels
-  // Keep the obstacle table in LDS while a workgroup stays within 32 KiB (≥ 5 solves resident per CU of 160 KiB).
   const size_t tab_bytes = (size_t)a.M * TABF * a.N * sizeof(double);
-  const bool tab_lds = a.n_samples == 0 && lds + tab_bytes <= 32 * 1024;  // (M = 0: an empty table fits)
+  const bool tab_lds = a.n_samples == 0 && solve_table_in_lds(a.N, a.M, a.kp.n_samples);
   if (a.n_samples > 0) {  // sampled obstacles: offset records in LDS, nominal records in the global workspace
     const size_t extra = solve_sampled_lds_bytes(a.M, a.n_samples);
     if (lds + extra > SOLVE_LDS_MAX) return hipErrorInvalidValue;  // checked by the caller
@@ -1734,8 +1997,10 @@ hipError_t launch_solve_wave(const SolveArgs& a, hipStream_t stream) {
   }
   if (lds > SOLVE_LDS_MAX) return hipErrorInvalidValue;  // checked by the caller
   const size_t extra = tab_lds ? tab_bytes : 0;
-  if (tab_lds && a.pair && !a.unc.layer && (a.flags & CILQR_FLAG_FAITHFUL_ITERS) == 0)
+  if (tab_lds && a.pair == 1 && !a.unc.layer && (a.flags & CILQR_FLAG_FAITHFUL_ITERS) == 0)
     return a.diag ? launch_two_wavefronts<true>(a, tab_bytes, stream) : launch_two_wavefronts<false>(a, tab_bytes, stream);
+  if (a.pair == 2 && a.n_samples == 0 && solve_share_applies(a.N, a.M, a.kp.n_samples) && !a.unc.layer && (a.flags & CILQR_FLAG_FAITHFUL_ITERS) == 0)
+    return a.diag ? launch_shared_L<true>(a, tab_bytes, stream) : launch_shared_L<false>(a, tab_bytes, stream);
   if (a.diag) return tab_lds ? launch_pair<true, 1>(a, extra, stream) : launch_pair<true, 0>(a, extra, stream);
   return tab_lds ? launch_pair<false, 1>(a, extra, stream) : launch_pair<false, 0>(a, extra, stream);
 }
