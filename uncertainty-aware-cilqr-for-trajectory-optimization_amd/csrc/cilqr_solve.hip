@@ -1637,41 +1637,43 @@ __global__ __launch_bounds__(2 * WAVE, 2) void cilqr_solve_share_kernel(SolveArg
   int* const cmd = reinterpret_cast<int*>(ctl);
   double* fwd = a.fwd + (size_t)b * (N + 1) * FREC;
 
-  // ---- prologue, both wavefronts -----------------------------------------------------------------------------------------------
+  // ---- prologue: the controls by both wavefronts; then the nominal rollout on the main wavefront while the aux wavefront fills the
+  // path samples and the obstacle table (the rollout needs neither) ------------------------------------------------------------------
   SampleGrid grid;
   make_sample_grid(grid, a.xplan_fl[2 * b], a.xplan_fl[2 * b + 1], S);
-  {
-    const double* pc = a.poly + (size_t)b * CILQR_POLY_COEFFS;
-    for (int s = tid; s < S; s += 2 * WAVE) {
-      double xs;
-      sample_xy(grid, pc, s, xs, samp[s]);
-    }
-  }
   const double* Ug = a.U + (size_t)b * 2 * N;
   for (int i = tid; i < 2 * N; i += 2 * WAVE) Ua[i] = Ug[i];
   if (tid < 16 && (tid & 7) < 5) cst[(tid & 7) + (tid >> 3) * RECF] = (tid & 7) == 0 ? 0.0 : (tid & 7) == 1 ? 1.0 : (tid & 7) == 2 ? kp.dt : (tid & 7) == 3 ? kp.w_vel * 2 : 2.0;
   if (tid == 0) cmd[0] = 0;
-  for (int i = tid; i < M * N; i += 2 * WAVE) {  // obstacle table, I/Obstacle.cpp:41-62 (entry i = m·N + t, as the inputs lie)
-    const ObsEntry e = make_obs_entry(kp, a.obs_pose + ((size_t)b * M * N + i) * 4, a.obs_dim + ((size_t)b * M * N + i) * 2);
-    double* o = tab + (size_t)i * TABF;
-    o[0] = e.ox; o[1] = e.oy; o[2] = e.co; o[3] = e.so; o[4] = e.ia2; o[5] = e.ib2;
-  }
   const double* wts = a.obs_weight ? a.obs_weight + (size_t)b * M : nullptr;
-  __syncthreads();
+  __syncthreads();  // the controls are in LDS
   bool handover = false;
   if (wave == 0) {
-    {  // largest step between adjacent path samples in y: closest_sample's second window (cilqr_device.hpp)
-      double m = 0.0;
-      for (int q = lane; q + 1 < S; q += WAVE) {
-        const double d = fabs(samp[q + 1] - samp[q]);
-        m = fmax(m, d == d ? d : __builtin_huge_val());
-      }
-      grid.dmax = wave_max_uniform(m);
-    }
     handover = !rollout_fast(kp, N, a.x0 + (size_t)b * 4, Ua, Xa);  // nominal rollout, I/iLQR.cpp:51-62
     if (handover && lane == 0) *reinterpret_cast<volatile int*>(cmd) = CMD_EXIT;
+  } else {
+    const double* pc = a.poly + (size_t)b * CILQR_POLY_COEFFS;
+    for (int s = lane; s < S; s += WAVE) {
+      double xs;
+      sample_xy(grid, pc, s, xs, samp[s]);
+    }
+    for (int i = lane; i < M * N; i += WAVE) {  // obstacle table, I/Obstacle.cpp:41-62 (entry i = m·N + t, as the inputs lie)
+      const ObsEntry e = make_obs_entry(kp, a.obs_pose + ((size_t)b * M * N + i) * 4, a.obs_dim + ((size_t)b * M * N + i) * 2);
+      double* o = tab + (size_t)i * TABF;
+      o[0] = e.ox; o[1] = e.oy; o[2] = e.co; o[3] = e.so; o[4] = e.ia2; o[5] = e.ib2;
+    }
+    // largest step between adjacent path samples in y: closest_sample's second window (cilqr_device.hpp); to the main wavefront through LDS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the samples: written above by lanes of this wavefront)
+    double m = 0.0;
+    for (int q = lane; q + 1 < S; q += WAVE) {
+      const double d = fabs(samp[q + 1] - samp[q]);
+      m = fmax(m, d == d ? d : __builtin_huge_val());
+    }
+    m = wave_max_uniform(m);
+    if (lane == 0) ctl[1] = m;
   }
-  __syncthreads();  // the trajectory is in LDS
+  __syncthreads();  // trajectory, samples and table are in LDS
+  grid.dmax = ctl[1];
 
   const int t = lane;
   const bool act = t < N;
