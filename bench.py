@@ -165,7 +165,7 @@ def bench_warp(args, rank, local_rank, world, dist, dev):
                "data": "synthetic",
                "config": {"workload": ("BASELINE config 4: " if S == 1024 else "size sweep: ") +
                                       "%dx%d occupancy costmap warp, %d frame(s) per step and launch, maps resident in HBM" % (S, S, K)},
-               "roofline": {"bound": "hbm", "kernel": "warp_kernel" if K == 1 else "warp_batch_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+               "roofline": {"bound": "hbm", "kernel": "warp_batch_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": recorded_traffic("warp" if K == 1 else "warp%d" % K, S)[0],
                             "traffic_source": recorded_traffic("warp" if K == 1 else "warp%d" % K, S)[1],
                             "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch}}
@@ -533,10 +533,11 @@ def bench_c1(args, rank, local_rank, world, dist, dev):
                           "iterations": int(got["iters"][0]), "exit": int(got["status"][0])},
                "latency_ms": {"median": 1e3 * med, "p10": 1e3 * float(np.percentile(lat, 10)), "p90": 1e3 * float(np.percentile(lat, 90)),
                               "min": 1e3 * float(lat.min())},
-               "roofline": {"bound": "hbm", "kernel": "cilqr_solve_kernel", "achieved": bytes_launch / (kern_ms * 1e-3) / 1e9,
+               "roofline": {"bound": "hbm", "kernel": "cilqr_solve_share_kernel" if solver.solve_wavefronts(1, N, M) == 2 else "cilqr_solve_kernel",
+                            "achieved": bytes_launch / (kern_ms * 1e-3) / 1e9,
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_launch / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "traffic": None, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch,
-                            "note": "one wavefront on one SIMD: pure serial-chain latency, the rest of the chip idle"}}
+                            "note": "one solve on one CU (two wavefronts while it linearises, one otherwise): pure serial-chain latency, the rest of the chip idle"}}
         if not args.no_cpu_baseline and world == 1:
             from oracle import oracle as O
             O.build(ref=False)
