@@ -533,7 +533,7 @@ def bench_c1(args, rank, local_rank, world, dist, dev):
                           "iterations": int(got["iters"][0]), "exit": int(got["status"][0])},
                "latency_ms": {"median": 1e3 * med, "p10": 1e3 * float(np.percentile(lat, 10)), "p90": 1e3 * float(np.percentile(lat, 90)),
                               "min": 1e3 * float(lat.min())},
-               "roofline": {"bound": "hbm", "kernel": "cilqr_solve_share_kernel" if solver.solve_wavefronts(1, N, M) == 2 else "cilqr_solve_kernel",
+               "roofline": {"bound": "hbm", "kernel": "cilqr_solve_share_kernel<%d>" % solver.solve_wavefronts(1, N, M) if solver.solve_wavefronts(1, N, M) >= 2 else "cilqr_solve_kernel",
                             "achieved": bytes_launch / (kern_ms * 1e-3) / 1e9,
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_launch / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "traffic": None, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch,
@@ -750,8 +750,8 @@ def main():
         # which kernel family the library picks for this shape: asked, not restated (cilqr_solve_family)
         lanes = 64 if sampled else solver.solve_family(B, N, M)
         kernel_name = "cilqr_solve_kernel" if lanes == 64 else "cilqr_solve_groups_fast<%d>" % lanes
-        if not sampled and lanes == 64 and solver.solve_wavefronts(B, N, M) == 2:
-            kernel_name = "cilqr_solve_share_kernel"
+        if not sampled and lanes == 64 and solver.solve_wavefronts(B, N, M) >= 2:
+            kernel_name = "cilqr_solve_share_kernel<%d>" % solver.solve_wavefronts(B, N, M)
         if sampled and solver.solve_sampled_wavefronts(B, N, n_dyn) > 1:
             kernel_name = "cilqr_solve_split_kernel<%d>" % solver.solve_sampled_wavefronts(B, N, n_dyn)
         traffic, traffic_tag = (None, None) if (args.workload == "c3" and args.materialised) else recorded_traffic(args.workload, B)

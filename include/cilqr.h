@@ -368,11 +368,12 @@ int cilqr_set_pass_count_buffer(cilqr_handle* h, int32_t* dev_buf);
  * wavefront.  The same rule cilqr_solve_batch(_device) applies (CILQR_FORCE_G in the environment at create overrides it);
  * measurement tools label their figures with it instead of restating the rule.  Negative: error code. */
 int cilqr_solve_family(const cilqr_handle* h, int B, int N, int M);
-/* Wavefronts per solve of cilqr_solve_batch(_device) on the one-wavefront family: 2 where a second wavefront takes the obstacle and
- * Jacobian terms of phase L while the first searches the closest path samples (cilqr_solve_share_kernel, DESIGN.md §4.2: batches
- * of up to two solves per SIMD, obstacle table in LDS, N ≤ 63, no uncertainty map; results bit-identical to the one-wavefront
- * kernel; CILQR_NO_SHARE_KERNEL in the environment at create switches it off), else 1 (also for every shape cilqr_solve_family
- * sends to the grouped family).  CILQR_FLAG_FAITHFUL_ITERS always runs on one.  Negative: error code. */
+/* Wavefronts per solve of cilqr_solve_batch(_device) on the one-wavefront family: 2 or 3 where further wavefronts take the obstacle,
+ * Jacobian and control-barrier terms of phase L while the first searches the closest path samples (cilqr_solve_share_kernel, DESIGN.md
+ * §4.2: three up to one solve per SIMD and at least two obstacles, two up to two solves per SIMD; obstacle table in LDS, N ≤ 63, no
+ * uncertainty map; results bit-identical to the one-wavefront kernel; CILQR_NO_SHARE_KERNEL in the environment at create switches it
+ * off, CILQR_SHARE_W = 2 or 3 fixes the number), else 1 (also for every shape cilqr_solve_family sends to the grouped family).
+ * CILQR_FLAG_FAITHFUL_ITERS always runs on one.  Negative: error code. */
 int cilqr_solve_wavefronts(const cilqr_handle* h, int B, int N, int M);
 /* The same for cilqr_solve_batch_sampled(_device): how many wavefronts share a solve's phase L on this handle — 1 (one wavefront
  * per solve: horizons beyond 64, a set uncertainty map, CILQR_NO_SPLIT_KERNEL), 2 or 4 (cilqr_solve_split_kernel, DESIGN.md

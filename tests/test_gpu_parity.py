@@ -494,19 +494,26 @@ def _same_bits(got, ref, what):
         assert np.array_equal(got[k], ref[k], equal_nan=(k in ("U", "X", "J"))), "%s: %s differs" % (what, k)
 
 
-@pytest.mark.parametrize("N,M,B", [(50, 4, 1024), (50, 4, 2048), (30, 2, 200), (2, 1, 9), (1, 1, 3), (3, 0, 5), (17, 5, 64), (63, 4, 96), (33, 9, 70)])
+@pytest.mark.parametrize("N,M,B", [(50, 4, 1024), (50, 4, 2048), (30, 2, 200), (2, 1, 9), (1, 1, 3), (3, 0, 5), (17, 5, 64), (63, 4, 96), (33, 9, 70), (40, 3, 33)])
 def test_share_kernel_changes_no_bit(cilqr, oracle, monkeypatch, N, M, B):
-    """Up to two solves per SIMD a static-obstacle solve runs as a workgroup of two wavefronts that work on phase L at the same time
-    (cilqr_solve_share_kernel: closest samples, tracking terms, control barrier on one; cos / sin, obstacle sums, Jacobians on the
-    other).  The statements are lin_step's, the obstacle terms are summed from zero in every kernel: U, X, J, iterations and exit
+    """Up to two solves per SIMD a static-obstacle solve runs as a workgroup of two or three wavefronts that work on phase L at the same
+    time (cilqr_solve_share_kernel: closest samples and tracking terms on one; cos / sin, obstacle sums — with three wavefronts the
+    entries of even index on one, of odd index on the other —, Jacobians and control barrier on the others).  The statements are
+    lin_step's, whose obstacle terms are summed from zero in an even and an odd chain in every kernel: U, X, J, iterations and exit
     reasons must be BIT-IDENTICAL to the one-wavefront kernel's — config 2 in full, two solves per SIMD, and ragged shapes
-    (N = 1, 2, 63; no obstacles; more obstacles than fit a round number) — and agree with the oracle."""
+    (N = 1, 2, 63; no obstacles, one, odd counts) — with three wavefronts and with two, and agree with the oracle."""
     from cilqr_amd import scenes
     p = cilqr.default_params(N)
     sc = scenes.make_static(B, N, M, p, 7300 + N)
     got, ref, w2, w1 = _share_vs_single(cilqr, monkeypatch, sc, N, M, B)
-    assert (w2, w1) == (2, 1)
-    _same_bits(got, ref, "two wavefronts sharing phase L against one")
+    assert (w2, w1) == (3 if B <= 1024 and M >= 2 else 2, 1)  # (MI355X: 1024 SIMDs)
+    _same_bits(got, ref, "%d wavefronts sharing phase L against one" % w2)
+    if w2 == 3:  # the other wavefront count on the same shape
+        monkeypatch.setenv("CILQR_SHARE_W", "2")
+        got2, _, w, _ = _share_vs_single(cilqr, monkeypatch, sc, N, M, B)
+        monkeypatch.delenv("CILQR_SHARE_W")
+        assert w == 2
+        _same_bits(got2, ref, "two wavefronts sharing phase L against one")
     idx = np.arange(min(B, 128))
     sub = {k: (v[idx] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in sc.items()}
     _compare({k: v[idx] for k, v in got.items()}, _oracle_batch(oracle, N, sub), TIGHT, "two wavefronts sharing phase L")
@@ -533,7 +540,7 @@ def test_share_kernel_weights_warm_starts_and_hand_over(cilqr, oracle, monkeypat
     sc["x0"][7, 2] = 25.0
     sc["U"][7, 1::2] = 5.0  # full lock at 25 m/s: more than 1/4 rad per step
     got, ref, w2, w1 = _share_vs_single(cilqr, monkeypatch, sc, N, M, B)
-    assert (w2, w1) == (2, 1)
+    assert (w2, w1) == (3, 1)
     _same_bits(got, ref, "shared phase L, weights and warm starts")
     keep = np.ones(B, bool)
     keep[[3]] = False
@@ -542,7 +549,8 @@ def test_share_kernel_weights_warm_starts_and_hand_over(cilqr, oracle, monkeypat
     s = cilqr.Solver(cilqr.default_params(64), max_batch=8192, max_horizon=64, max_obstacles=4, device=0)
     try:
         simds = 1024  # MI355X: 256 CUs × 4
-        assert s.solve_wavefronts(64, 64, 4) == 1 and s.solve_wavefronts(64, 63, 4) == 2
+        assert s.solve_wavefronts(64, 64, 4) == 1 and s.solve_wavefronts(64, 63, 4) == 3 and s.solve_wavefronts(64, 63, 1) == 2
+        assert s.solve_wavefronts(simds, 50, 4) == 3 and s.solve_wavefronts(simds + 1, 50, 4) == 2
         assert s.solve_wavefronts(2 * simds, 50, 4) == 2 and s.solve_wavefronts(2 * simds + 1, 50, 4) == 1
         assert s.solve_wavefronts(64, 50, 40) == 1  # (the table of 40 obstacles × 50 steps does not fit the LDS share of a solve)
     finally:

@@ -47,8 +47,10 @@ w = int(np.argmax(d[:, 7]))
 print("slowest solve %d: pro %d L %d R %d F %d epi %d nL %d nR %d total %d" % ((w,) + tuple(int(v) for v in d[w][:8])))
 if os.environ.get("SHARE"):  # shared-phase-L kernel: slots 8..10 = aux busy ticks, aux calls, main's wait at barrier A
     k = np.maximum(d[:, 9], 1)
-    print("aux wavefront: %.0f ticks per linearisation (calls mean %.1f) | main waits %.0f ticks per linearisation at barrier A"
-          % ((d[:, 8] / k).mean(), d[:, 9].mean(), (d[:, 10] / nL).mean()))
+    print("aux wavefront: %.0f ticks per linearisation (calls mean %.1f) | second aux wavefront %.0f | main waits %.0f ticks per linearisation at barrier A"
+          % ((d[:, 8] / k).mean(), d[:, 9].mean(), (d[:, 11] / k).mean(), (d[:, 10] / nL).mean()))
+    w = int(np.argmax(d[:, 7]))
+    print("slowest solve %d: aux %.0f / %.0f ticks per linearisation, main waits %.0f" % (w, d[w, 8] / k[w], d[w, 11] / k[w], d[w, 10] / nL[w]))
 elif os.environ.get("PAIR"):  # two-wavefront kernel: slots 8..11 are the aux wavefront's account
     k = d[:, 11]
     print("aux wavefront, ticks per linearisation: waiting for states %.0f | chunk work %.0f | from the last state's arrival to its barrier %.0f  (calls mean %.1f)"

@@ -27,7 +27,7 @@ def short(name, n=90):
 
 
 # the dominant kernel of a workload: the first of these that a section's kernel names contain
-DOMINANT = {"c2": ["cilqr_solve_share_kernel<false", "cilqr_solve_kernel<false, 1, false", "cilqr_solve_kernel<false"],
+DOMINANT = {"c2": ["cilqr_solve_share_kernel", "cilqr_solve_kernel<false, 1, false", "cilqr_solve_kernel<false"],
             "c3": ["cilqr_solve_split_kernel", "cilqr_solve_kernel<false, 2, false", "cilqr_solve_kernel<false"],
             "c5": ["cilqr_solve_groups_fast", "cilqr_solve_kernel<false, 0, false"],
             "warp": ["warp_batch_kernel", "warp_kernel"], "warp16": ["warp_batch_kernel", "warp"],

@@ -3,7 +3,8 @@
 against the one-wavefront kernel on config-2 scenes: bit differences (there must be none) and kernel time by HIP events, over
 a range of batch sizes.  Both handles solve the same inputs, taking turns in going first.
 
-    python tools/share_ab.py [N] [M] [B ...]      default N = 50, M = 4, B = 1 64 256 512 768 1024 1536 2048
+    [SHARE_W=2|3] python tools/share_ab.py [N] [M] [B ...]      default N = 50, M = 4, B = 1 64 256 512 768 1024 1536 2048
+    (SHARE_W fixes the number of wavefronts per solve; default: the library's rule — three up to one solve per SIMD, else two)
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,8 +23,11 @@ print("config-2 scenes, N = %d, M = %d static obstacles; kernel pair (fast + GEN
 for B in BS:
     sc = scenes.make_static(B, N, M, p, scenes.SEED0 + 2)
     os.environ["CILQR_SHARE_MAX_B"] = str(1 << 30)  # the shared kernel at every batch size of this sweep
+    if os.environ.get("SHARE_W"):
+        os.environ["CILQR_SHARE_W"] = os.environ["SHARE_W"]
     two = cilqr_amd.Solver(p, max_batch=B, max_horizon=N, max_obstacles=max(M, 1))
     del os.environ["CILQR_SHARE_MAX_B"]
+    os.environ.pop("CILQR_SHARE_W", None)
     os.environ["CILQR_NO_SHARE_KERNEL"] = "1"
     one = cilqr_amd.Solver(p, max_batch=B, max_horizon=N, max_obstacles=max(M, 1))
     del os.environ["CILQR_NO_SHARE_KERNEL"]
@@ -48,8 +52,8 @@ for B in BS:
     a, b = bufs["two"], bufs["one"]
     same = all(torch.equal(a[k], b[k]) for k in ("U", "X", "J", "it", "st"))
     ta, tb = sorted(a["ms"]), sorted(b["ms"])
-    print("B = %5d: two wavefronts %.4f / %.4f ms | one %.4f / %.4f ms | ratio of medians %.3f | bit-identical: %s | families %s / %s"
-          % (B, ta[0], ta[len(ta) // 2], tb[0], tb[len(tb) // 2], ta[len(ta) // 2] / tb[len(tb) // 2], same,
+    print("B = %5d: %d wavefronts %.4f / %.4f ms | one %.4f / %.4f ms | ratio of medians %.3f | bit-identical: %s | families %s / %s"
+          % (B, two.solve_wavefronts(B, N, M), ta[0], ta[len(ta) // 2], tb[0], tb[len(tb) // 2], ta[len(ta) // 2] / tb[len(tb) // 2], same,
              two.solve_family(B, N, M), one.solve_family(B, N, M)), flush=True)
     if not same:
         for k in ("U", "X", "J"):

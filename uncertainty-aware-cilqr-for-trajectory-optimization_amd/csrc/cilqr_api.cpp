@@ -112,7 +112,13 @@ static int pick_split_wavefronts(const cilqr_handle* h, int B) {
 // Static obstacles on the one-wavefront family: a second wavefront per solve for phase L (cilqr_solve_share_kernel) up to TWO solves per
 // SIMD — tools/share_ab.py, profiles/r03_share_kernel.txt: config-2 scenes 0.372 against 0.404 ms at B = 256, 0.390 / 0.415 at 1024,
 // 0.406 / 0.433 at 2048, level at 3072, slower at 4096 (0.547 / 0.476: the second wavefronts cost residency there).
-static bool pick_share(const cilqr_handle* h, int B) { return !h->share_off && B <= h->share_max; }
+// Up to ONE solve per SIMD three: the obstacle terms on two of them (even / odd entries: obstacle_loop's own two chains), Jacobians and
+// control barrier on the last — the solves that decide such a launch are the ones with every obstacle close.  0: one wavefront.
+static int pick_share(const cilqr_handle* h, int B, int M) {
+  if (h->share_off || B > h->share_max) return 0;
+  const int w = h->share_w ? h->share_w : (B <= h->simds ? 3 : 2);
+  return w == 3 && M < 2 ? 2 : w;
+}
 
 // The one-wavefront-per-solve family with a schedule hint.  A batch of more solves than SIMDs is dispatched in workgroup order,
 // and its launch ends when the last workgroup does: a 20-pass solve that starts among the last costs its full length on top of
@@ -132,7 +138,7 @@ static int launch_wave_scheduled(cilqr_handle* h, cilqr::SolveArgs& a, void* str
   // Default up to one solve per SIMD (share_max solves): a second wavefront per solve takes the obstacle, control-barrier and Jacobian
   // terms of phase L while the first searches the closest samples (cilqr_solve_share_kernel; bit-identical results; the launcher
   // falls back where it does not apply: table not in LDS, N > 63, a map set, the reference-loop mode).
-  if (!a.pair && pick_share(h, a.B)) a.pair = 2;
+  if (!a.pair) a.pair = pick_share(h, a.B, a.M);
   HIP_TRY(cilqr::launch_solve_wave(a, (hipStream_t)stream));
   if (hinted) {
     HIP_TRY(cilqr::launch_schedule_order(h->d_hint_passes, a.B, h->d_order, (hipStream_t)stream));
@@ -247,6 +253,7 @@ int cilqr_create(const cilqr_params* p, int max_batch, int max_horizon, int max_
   h->split_off = getenv("CILQR_NO_SPLIT_KERNEL") != nullptr;
   h->share_off = getenv("CILQR_NO_SHARE_KERNEL") != nullptr;
   h->share_max = 2 * h->simds;
+  if (const char* sw = getenv("CILQR_SHARE_W")) h->share_w = atoi(sw) == 3 ? 3 : 2;  // (A/B hook: two or three wavefronts wherever the kernel applies)
   if (const char* sm = getenv("CILQR_SHARE_MAX_B")) h->share_max = atoi(sm);  // (A/B hook: largest batch on the shared-phase-L kernel)
   if (const char* sw = getenv("CILQR_SPLIT_W")) h->split_w = atoi(sw);  // (test hook: 2 or 4 wavefronts per solve)
   if (err == hipSuccess) err = dmalloc(&h->d_pair, (size_t)2);
@@ -431,7 +438,8 @@ int cilqr_solve_family(const cilqr_handle* h, int B, int N, int M) {
 int cilqr_solve_wavefronts(const cilqr_handle* h, int B, int N, int M) {
   if (!h || B < 0 || N < 1 || M < 0) return fail(CILQR_ERR_ARG, "cilqr_solve_wavefronts: bad argument");
   if (pick_group_lanes(h, B, N, M) != 64) return 1;
-  return pick_share(h, B) && !h->pair_on && !h->unc.layer && cilqr::solve_share_applies(N, M, h->kp.n_samples) ? 2 : 1;
+  const int w = pick_share(h, B, M);
+  return w && !h->pair_on && !h->unc.layer && cilqr::solve_share_applies(N, M, h->kp.n_samples) ? w : 1;
 }
 
 int cilqr_solve_sampled_wavefronts(const cilqr_handle* h, int B, int N, int n_obs) {

@@ -280,6 +280,8 @@ __device__ __forceinline__ void forward_step(const FwdConst& k, const FwdIn& c, 
 struct SampleGrid {
   double xf, dxs, inv_dxs;  // inv_dxs = 1/dxs (signed)
   double dmax;              // largest |y_{s+1} - y_s| over the samples (set once per solve; +inf: not known)
+  double p2;                // an upper bound of |p''| over the sampled range (path_curvature_bound; +inf: not known → no Newton search)
+  const double* pc;         // the polynomial's coefficients, ascending (null: no Newton search)
   bool windowed;            // false: dxs is 0 or not finite → full scan
 };
 __device__ __forceinline__ void make_sample_grid(SampleGrid& g, double xf, double xl, int S) {
@@ -287,7 +289,36 @@ __device__ __forceinline__ void make_sample_grid(SampleGrid& g, double xf, doubl
   g.dxs = (xl - xf) / (double)S;
   g.inv_dxs = 1.0 / g.dxs;
   g.dmax = __builtin_huge_val();
+  g.p2 = __builtin_huge_val();
+  g.pc = nullptr;
   g.windowed = fabs(g.inv_dxs) < 1.0e300 && fabs(g.dxs) < 1.0e300 && g.dxs != 0.0;
+}
+// Value, first and second derivative of the path polynomial at x (Horner from the top; for the Newton search below — the SAMPLES are
+// formed by sample_xy alone).
+__device__ __forceinline__ void poly_012(const double* pc, double x, double& p, double& d1, double& d2) {
+  double b = pc[CILQR_POLY_COEFFS - 1], c = 0.0, d = 0.0;
+#pragma unroll
+  for (int j = CILQR_POLY_COEFFS - 2; j >= 0; --j) {
+    d = fma(d, x, c);
+    c = fma(c, x, b);
+    b = fma(b, x, pc[j]);
+  }
+  p = b; d1 = c; d2 = d + d;
+}
+// One sample's contribution to an upper bound of the second derivative over the sampled range [x_0, x_{S-1}]: |p2| and |p3| (second
+// and third derivative) at x.  With A = max_s |p2(x_s)|, B = max_s |p3(x_s)| and C = max |p4| over the range (the fourth derivative
+// is linear: its endpoints), Taylor between neighbouring samples gives |p2| ≤ A + (h/2)(B + (h/2) C) on the whole range
+// (path_curvature_bound puts them together).
+static_assert(CILQR_POLY_COEFFS == 6, "the curvature bound is written for the reference's degree-5 local plan");
+__device__ __forceinline__ void path_curvature_terms(const double* pc, double x, double& a2, double& a3) {
+  a2 = fabs(fma(fma(fma(20.0 * pc[5], x, 12.0 * pc[4]), x, 6.0 * pc[3]), x, 2.0 * pc[2]));
+  a3 = fabs(fma(fma(60.0 * pc[5], x, 24.0 * pc[4]), x, 6.0 * pc[3]));
+}
+__device__ __forceinline__ double path_curvature_bound(const SampleGrid& g, const double* pc, int S, double A, double B) {
+  const double x0 = g.xf, x1 = fma(g.dxs, (double)(S - 1), g.xf), hh = 0.5 * fabs(g.dxs);
+  const double C = fmax(fabs(fma(120.0 * pc[5], x0, 24.0 * pc[4])), fabs(fma(120.0 * pc[5], x1, 24.0 * pc[4])));
+  const double P = (A + hh * (B + hh * C)) * (1.0 + 1.0e-6);
+  return P == P ? P : __builtin_huge_val();  // (a NaN anywhere: not known)
 }
 __device__ __forceinline__ void sample_xy(const SampleGrid& g, const double* pc, int s, double& x, double& y) {
   x = fma(g.dxs, (double)s, g.xf);
@@ -314,51 +345,66 @@ __device__ __forceinline__ double sample_dist(SampleAt at, int s, double px, dou
   return (sx - px) * (sx - px) + (sy - py) * (sy - py);
 }
 
-// The index window [lo, hi] that contains the argmin (see closest_sample): one statement of it for every search.
+// The index window [lo, hi] that contains the argmin (see closest_sample): one statement of it for every search, in two parts.
+// First part, from the x side (always a superset of the argmin's neighbourhood).  Also hands back what the refinements need:
+// c = the sample nearest in x, its position, its squared distance dc, the half-width hw (in samples; < 0: no window, full range).
+struct XWindow {
+  int lo, hi, c;
+  double scx, scy, dc, hw;
+};
+template <typename SampleAt>
+__device__ __forceinline__ XWindow closest_window_x(int S, const SampleGrid& g, double px, double py, SampleAt at) {
+  XWindow w;
+  w.lo = 0; w.hi = S - 1; w.c = 0; w.scx = 0.0; w.scy = 0.0; w.dc = 0.0; w.hw = -1.0;
+  if (g.windowed) {
+    const double fc = (px - g.xf) * g.inv_dxs;
+    const double fcc = fmin(fmax(fc, 0.0), (double)(S - 1));  // NaN → 0
+    w.c = (int)(fcc + 0.5);
+    at(w.c, w.scx, w.scy);
+    w.dc = sample_dist(at, w.c, px, py);
+    const double hw = (double)(__builtin_sqrtf((float)w.dc) * 1.0001f) * fabs(g.inv_dxs) * 1.0001 + 2.0;
+    if (hw < 1.0e9) {  // false for NaN / overflow: keep the full range
+      w.lo = (int)fmin(fmax(fc - hw, 0.0), (double)(S - 1));
+      w.hi = (int)fmax(fmin(fc + hw + 1.0, (double)(S - 1)), 0.0);
+      w.hw = hw;
+    }
+  }
+  return w;
+}
+// Second, usually much tighter window from the y side.  Sample c + n (or c - n) has |x_s - px| ≥ n·h - e and, by the
+// triangle inequality over adjacent samples, |y_s - py| ≥ Ly - n·D, with h = |dxs|, e = |x_c - px|, Ly = |y_c - py|,
+// D = dmax.  While both right-hand sides are non-negative, d_s ≥ (n h - e)² + (Ly - n D)²; a sample can only reach
+// d_c if that is ≤ d_c, i.e. n ≤ [B + sqrt(B² + A (T - e² - Ly²))] / A with A = h² + D², B = h e + Ly D.  Used only when
+// the y-bound stays non-negative across the whole first window (D·hw ≤ Ly) and c really is the sample nearest in x
+// (e ≤ h); widened by a 1e-9 relative margin and two samples, like the first window ≫ any rounding in its terms.
+__device__ __forceinline__ void closest_window_y(int S, const SampleGrid& g, double px, double py, XWindow& w) {
+  if (!(w.hw >= 0.0)) return;
+  const double h = fabs(g.dxs), D = g.dmax, e = fabs(w.scx - px), Ly = fabs(w.scy - py);
+  if (D * w.hw <= Ly && e <= h) {
+    const double A = h * h + D * D, Bq = h * e + Ly * D;
+    const double T = w.dc * (1.0 + 1.0e-9);
+    const double disc = Bq * Bq + A * (T - e * e - Ly * Ly);
+    const double nmax = (Bq + sqrt(fmax(disc, 0.0))) / A * (1.0 + 1.0e-9) + 2.0;
+    if (nmax < 1.0e9) {  // false for NaN
+      w.lo = max(w.lo, (int)fmax((double)w.c - nmax, 0.0));
+      w.hi = min(w.hi, (int)fmin((double)w.c + nmax + 1.0, (double)(S - 1)));
+    }
+  }
+}
 // YSIDE = false leaves out the second (y-side) window: still a superset of the argmin's neighbourhood, i.e. the same argmin; worth
 // it where the scan is dealt to several lanes and the window's square root and division cost more than the candidates they save.
 template <bool YSIDE = true, typename SampleAt>
 __device__ __forceinline__ void closest_window(int S, const SampleGrid& g, double px, double py, SampleAt at, int& lo, int& hi) {
-  auto dist = [&](int s) { return sample_dist(at, s, px, py); };
-  lo = 0;
-  hi = S - 1;
-  if (g.windowed) {
-    const double fc = (px - g.xf) * g.inv_dxs;
-    const double fcc = fmin(fmax(fc, 0.0), (double)(S - 1));  // NaN → 0
-    const int c = (int)(fcc + 0.5);
-    double scx, scy;
-    at(c, scx, scy);
-    const double dc = dist(c);
-    const double hw = (double)(__builtin_sqrtf((float)dc) * 1.0001f) * fabs(g.inv_dxs) * 1.0001 + 2.0;
-    if (hw < 1.0e9) {  // false for NaN / overflow: keep the full range
-      lo = (int)fmin(fmax(fc - hw, 0.0), (double)(S - 1));
-      hi = (int)fmax(fmin(fc + hw + 1.0, (double)(S - 1)), 0.0);
-      // Second, usually much tighter window from the y side.  Sample c + n (or c - n) has |x_s - px| ≥ n·h - e and, by the
-      // triangle inequality over adjacent samples, |y_s - py| ≥ Ly - n·D, with h = |dxs|, e = |x_c - px|, Ly = |y_c - py|,
-      // D = dmax.  While both right-hand sides are non-negative, d_s ≥ (n h - e)² + (Ly - n D)²; a sample can only reach
-      // d_c if that is ≤ d_c, i.e. n ≤ [B + sqrt(B² + A (T - e² - Ly²))] / A with A = h² + D², B = h e + Ly D.  Used only when
-      // the y-bound stays non-negative across the whole first window (D·hw ≤ Ly) and c really is the sample nearest in x
-      // (e ≤ h); widened by a 1e-9 relative margin and two samples, like the first window ≫ any rounding in its terms.
-      const double h = fabs(g.dxs), D = g.dmax, e = fabs(scx - px), Ly = fabs(scy - py);
-      if (YSIDE && D * hw <= Ly && e <= h) {
-        const double A = h * h + D * D, Bq = h * e + Ly * D;
-        const double T = dc * (1.0 + 1.0e-9);
-        const double disc = Bq * Bq + A * (T - e * e - Ly * Ly);
-        const double nmax = (Bq + sqrt(fmax(disc, 0.0))) / A * (1.0 + 1.0e-9) + 2.0;
-        if (nmax < 1.0e9) {  // false for NaN
-          lo = max(lo, (int)fmax((double)c - nmax, 0.0));
-          hi = min(hi, (int)fmin((double)c + nmax + 1.0, (double)(S - 1)));
-        }
-      }
-    }
-  }
+  XWindow w = closest_window_x(S, g, px, py, at);
+  if (YSIDE) closest_window_y(S, g, px, py, w);
+  lo = w.lo;
+  hi = w.hi;
 }
 
+// The scan over [lo, hi]: ascending, strict <.
 template <typename SampleAt>
-__device__ __forceinline__ int closest_sample(int S, const SampleGrid& g, double px, double py, SampleAt at) {
+__device__ __forceinline__ int closest_scan(int lo, int hi, double px, double py, SampleAt at) {
   auto dist = [&](int s) { return sample_dist(at, s, px, py); };
-  int lo, hi;
-  closest_window(S, g, px, py, at, lo, hi);
   double md = dist(lo);
   int best = lo;
   for (int s = lo + 1; s <= hi; s += 4) {
@@ -371,6 +417,60 @@ __device__ __forceinline__ int closest_sample(int S, const SampleGrid& g, double
     if (d3 < md) { md = d3; best = s3; }
   }
   return best;
+}
+
+// Wide windows (a state well off the path: the x-side window is as wide as the state is far, and most of that is lateral) by NEWTON
+// instead of a scan (round 3).  f(s) = (x_s - px)² + (p(x_s) - py)² as a function of a continuous s has f'' = 2h²·g with
+// g = 1 + p'² + (p - py)·p''.  Over the first window |p - py| ≤ Ly + D·(hw + 1) (adjacent samples differ by at most D = dmax in y)
+// and |p''| ≤ P2 (path_curvature_bound), so (Ly + D(hw + 1))·P2 ≤ ½ makes g ≥ ½ there: f is strictly convex over the whole window,
+// its values at the samples are a convex sequence with second differences ≥ h² — far above the rounding of a squared distance
+// (guarded: h² > 1e-9·(dc + 1)) — and a sample that is no larger than its evaluated neighbours on both sides (or sits at the
+// window's edge) is THE minimum over the window, hence over all samples; among equal values the ascending strict-< comparison keeps
+// the first, as the scan does.  Newton on phi(x) = (x - px) + (p - py)·p' (phi' = g ≥ ½) from the sample nearest in x, two steps
+// (the first is the projection onto the tangent at that sample), clamped to the window; then the four samples around its result are evaluated exactly as the scan evaluates them.  If the best of
+// them is not enclosed (Newton off by more than a sample) the scan runs after all.  Returns -1 where the conditions do not hold.
+constexpr int NEWTON_MIN_WINDOW = 16;
+template <typename SampleAt>
+__device__ __forceinline__ int closest_newton(int S, const SampleGrid& g, double px, double py, SampleAt at, const XWindow& w) {
+  if (!g.pc || !(w.hw >= 0.0)) return -1;
+  const double Ly = fabs(w.scy - py);
+  if (!((Ly + g.dmax * (w.hw + 1.0)) * g.p2 <= 0.5) || !(g.dxs * g.dxs > 1.0e-9 * (w.dc + 1.0))) return -1;
+  const double xa = fma(g.dxs, (double)w.lo, g.xf), xb = fma(g.dxs, (double)w.hi, g.xf);
+  const double xmin = fmin(xa, xb), xmax = fmax(xa, xb);
+  double x = w.scx;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    double p, d1, d2;
+    poly_012(g.pc, x, p, d1, d2);
+    const double phi = fma(p - py, d1, x - px), dphi = fma(p - py, d2, fma(d1, d1, 1.0));
+    x = fmin(fmax(fma(-phi, __builtin_amdgcn_rcp(dphi), x), xmin), xmax);
+  }
+  const double fs = (x - g.xf) * g.inv_dxs;
+  const int k = (int)fmin(fmax(floor(fs), (double)w.lo), (double)w.hi);  // NaN → lo
+  const int s0 = max(k - 1, w.lo), s1 = k, s2 = min(k + 1, w.hi), s3 = min(k + 2, w.hi);
+  const double d0 = sample_dist(at, s0, px, py), e1 = sample_dist(at, s1, px, py), e2 = sample_dist(at, s2, px, py),
+               e3 = sample_dist(at, s3, px, py);
+  double md = d0;
+  int best = s0;
+  if (e1 < md) { md = e1; best = s1; }
+  if (e2 < md) { md = e2; best = s2; }
+  if (e3 < md) { md = e3; best = s3; }
+  const bool enclosed = (best > s0 || s0 == w.lo) && (best < s3 || s3 == w.hi);
+  return enclosed ? best : -1;
+}
+
+// NEWTON = false: windows and scan only — the same argmin; for the instantiations that have no registers to spare for the second
+// search (the one-wavefront kernels sit at their 256-register budget) and for the rarely run paths.
+template <bool NEWTON = true, typename SampleAt>
+__device__ __forceinline__ int closest_sample(int S, const SampleGrid& g, double px, double py, SampleAt at) {
+  XWindow w = closest_window_x(S, g, px, py, at);
+  closest_window_y(S, g, px, py, w);
+  // Newton where the scan would visit more than ≈ 16 samples (its two steps and four candidates cost what ≈ 13 candidates do)
+  if (NEWTON && w.hi - w.lo >= NEWTON_MIN_WINDOW) {
+    const int fast = closest_newton(S, g, px, py, at, w);
+    if (fast >= 0) return fast;
+  }
+  return closest_scan(w.lo, w.hi, px, py, at);
 }
 
 // ---- cost linearisation of one step ----------------------------------------------------------------------------------
@@ -482,10 +582,13 @@ struct ObsConsts {  // what every obstacle entry of one step needs of the ego st
   double svf, smf, svr, smr;  // gradient / Hessian factors; the reference's factor -2 of c-dot (I/Obstacle.cpp:75-78) is carried
                               // here (exact: powers of two), not applied to the vector
 };
+// (from here to ab_terms: contraction is switched off and every fused multiply-add is written out — these statements are compiled
+// into several kernels, on different wavefronts of one solve, and must round alike in all of them)
 __device__ __forceinline__ ObsConsts make_obs_consts(const KParams& kp, double px, double py, double ct, double st) {
+#pragma clang fp contract(off)
   ObsConsts k;
-  k.fxp = px + ct * kp.ego_front; k.fyp = py + st * kp.ego_front;
-  k.rxp = px - ct * kp.ego_rear; k.ryp = py - st * kp.ego_rear;
+  k.fxp = __builtin_fma(ct, kp.ego_front, px); k.fyp = __builtin_fma(st, kp.ego_front, py);
+  k.rxp = __builtin_fma(-ct, kp.ego_rear, px); k.ryp = __builtin_fma(-st, kp.ego_rear, py);
   k.q2f = kp.q2_front; k.q2r = kp.q2_rear;
   k.svf = -2 * (kp.q2_front * kp.q1_front); k.smf = 4 * (kp.q2_front * kp.q2_front * kp.q1_front);
   k.svr = -2 * (kp.q2_rear * kp.q1_rear); k.smr = 4 * (kp.q2_rear * kp.q2_rear * kp.q1_rear);
@@ -496,14 +599,15 @@ struct ObsPrep {  // an entry up to its barrier arguments
 };
 // both circles up to the barrier argument c = 1 - d'Pd (I/Obstacle.cpp:65-73, 86-94)
 __device__ __forceinline__ void obs_prep(const ObsConsts& k, const ObsEntry& e, ObsPrep& p) {
+#pragma clang fp contract(off)
 #pragma unroll
   for (int side = 0; side < 2; ++side) {
     const double ex = (side == 0 ? k.fxp : k.rxp) - e.ox, ey = (side == 0 ? k.fyp : k.ryp) - e.oy;
-    const double d0 = e.co * ex + e.so * ey;
-    const double d1 = e.co * ey - e.so * ex;
+    const double d0 = __builtin_fma(e.co, ex, e.so * ey);
+    const double d1 = __builtin_fma(e.co, ey, -(e.so * ex));
     p.g0[side] = d0 * e.ia2;
     p.g1[side] = d1 * e.ib2;
-    const double c = 1 - (p.g0[side] * d0 + p.g1[side] * d1);
+    const double c = 1 - __builtin_fma(p.g0[side], d0, p.g1[side] * d1);
     p.arg[side] = (side == 0 ? k.q2f : k.q2r) * c;
   }
 }
@@ -513,19 +617,20 @@ struct ObsTerms {  // one entry's gradient and Hessian terms (front + rear circl
   double gx, gy, gxx, gxy, gyy;
 };
 __device__ __forceinline__ ObsTerms obs_terms(const ObsConsts& k, const ObsEntry& e, const ObsPrep& p) {
+#pragma clang fp contract(off)
   double gx = 0.0, gy = 0.0, gxx = 0.0, gxy = 0.0, gyy = 0.0;
 #pragma unroll
   for (int side = 0; side < 2; ++side) {
-    const double h0 = e.co * p.g0[side] - e.so * p.g1[side];  // c-dot = -2 (h0, h1)
-    const double h1 = e.so * p.g0[side] + e.co * p.g1[side];
+    const double h0 = __builtin_fma(e.co, p.g0[side], -(e.so * p.g1[side]));  // c-dot = -2 (h0, h1)
+    const double h1 = __builtin_fma(e.so, p.g0[side], e.co * p.g1[side]);
     const double ee = exp_fast(p.arg[side]);
     const double sv = (side == 0 ? k.svf : k.svr) * ee;
     const double sm = (side == 0 ? k.smf : k.smr) * ee;
-    gx += sv * h0;
-    gy += sv * h1;
-    gxx += (sm * h0) * h0;
-    gxy += (sm * h0) * h1;
-    gyy += (sm * h1) * h1;
+    gx = __builtin_fma(sv, h0, gx);
+    gy = __builtin_fma(sv, h1, gy);
+    gxx = __builtin_fma(sm * h0, h0, gxx);
+    gxy = __builtin_fma(sm * h0, h1, gxy);
+    gyy = __builtin_fma(sm * h1, h1, gyy);
   }
   return ObsTerms{gx, gy, gxx, gxy, gyy};
 }
@@ -547,6 +652,7 @@ __device__ __forceinline__ void obs_accumulate(StepSums& a, const ObsTerms& g, d
 // a lane of another wavefront (cilqr_solve.hip, cilqr_solve_share_kernel) — the record has the same bits.
 __device__ __forceinline__ void state_terms(const KParams& kp, double dx, double dy, const StepSums& a, double& lx0, double& lx1,
                                             double& l00, double& l01, double& l11) {
+#pragma clang fp contract(off)
   lx0 = __builtin_fma(2 * kp.w_pos, dx, a.lx0);
   lx1 = __builtin_fma(2 * kp.w_pos, dy, a.lx1);
   l00 = kp.w_pos * 2 + a.h00;
@@ -555,23 +661,26 @@ __device__ __forceinline__ void state_terms(const KParams& kp, double dx, double
 }
 // Control cost (I/Constraints.cpp:110-131): the arguments of its four barrier exponentials, then l_u, l_uu from their values.
 __device__ __forceinline__ void ctrl_args(const KParams& kp, double u0, double u1, double v, double& a1, double& a2, double& a3, double& a4) {
+#pragma clang fp contract(off)
   a1 = kp.q2_acc * (u0 - kp.acc_max);
   a2 = kp.q2_acc * (kp.acc_min - u0);
-  a3 = kp.q2_yawrate * (u1 - v * kp.yaw_hi);
-  a4 = kp.q2_yawrate * (v * kp.yaw_lo - u1);
+  a3 = kp.q2_yawrate * __builtin_fma(-v, kp.yaw_hi, u1);
+  a4 = kp.q2_yawrate * __builtin_fma(v, kp.yaw_lo, -u1);
 }
 __device__ __forceinline__ void ctrl_terms(const KParams& kp, double u0, double u1, double e1, double e2, double e3, double e4, Rec& r) {
+#pragma clang fp contract(off)
   const double sa = kp.q2_acc * kp.q1_acc, sy = kp.q2_yawrate * kp.q1_yawrate;
   const double ma = kp.q2_acc * kp.q2_acc * kp.q1_acc, my = kp.q2_yawrate * kp.q2_yawrate * kp.q1_yawrate;
-  r.lu0 = (sa * e1 - sa * e2) + (2 * kp.w_acc) * u0;
-  r.lu1 = (sy * e3 - sy * e4) + (2 * kp.w_yawrate) * u1;
-  r.luu0 = ma * e1 + ma * e2 + 2 * kp.w_acc;
-  r.luu1 = my * e3 + my * e4 + 2 * kp.w_yawrate;
+  r.lu0 = __builtin_fma(2 * kp.w_acc, u0, __builtin_fma(sa, e1, -(sa * e2)));
+  r.lu1 = __builtin_fma(2 * kp.w_yawrate, u1, __builtin_fma(sy, e3, -(sy * e4)));
+  r.luu0 = __builtin_fma(ma, e2, ma * e1) + 2 * kp.w_acc;
+  r.luu1 = __builtin_fma(my, e4, my * e3) + 2 * kp.w_yawrate;
 }
 // The six non-trivial Jacobian entries at (v_{t+1}, theta_{t+1}, a_t) (I/iLQR.cpp:102-106, I/Model.cpp:100-155)
 __device__ __forceinline__ void ab_terms(const KParams& kp, double u0, double vn, double cn, double sn, Rec& r) {
+#pragma clang fp contract(off)
   const double dt = kp.dt;
-  const double adv = vn * dt + u0 * kp.half_dt2;
+  const double adv = __builtin_fma(vn, dt, u0 * kp.half_dt2);
   r.al = dt * cn;            // A(2,0)
   r.be = dt * sn;            // A(2,1)
   r.ga = (-1) * sn * adv;    // A(3,0)
@@ -580,18 +689,23 @@ __device__ __forceinline__ void ab_terms(const KParams& kp, double u0, double vn
   r.q = kp.half_dt2 * sn;    // B(0,1)
 }
 
-// The obstacle terms of one step (I/Constraints.cpp:177-187, I/Obstacle.cpp:39-112) added to the sums `a`, entries 0 … M-1 of `obs`
-// in order: the loop of lin_step, on its own so that a second wavefront can evaluate a share of a step's entries
-// (cilqr_solve.hip, cilqr_solve_split_kernel).  CULL, PAIRED, LANE_EXACT: see lin_step.
-template <bool CULL, bool PAIRED, bool LANE_EXACT, typename ObsAt>
+// The obstacle terms of one step (I/Constraints.cpp:177-187, I/Obstacle.cpp:39-112) added to the sums `a`, entries 0 … M-1 of `obs`:
+// the loop of lin_step, on its own so that other wavefronts can evaluate a share of a step's entries (cilqr_solve.hip,
+// cilqr_solve_split_kernel, cilqr_solve_share_kernel).  CULL, PAIRED, LANE_EXACT: see lin_step.
+// SPLIT (the default): the entries with EVEN index are added up in one chain, in order, those with ODD index in another, and the
+// odd sum joins the even one at the end — two independent accumulation chains for a lone wavefront, and an order of summation that two
+// wavefronts can reproduce bit for bit, one taking the even entries, one the odd ones (each with SPLIT = false over its own
+// entries: one chain, in order).
+template <bool CULL, bool PAIRED, bool LANE_EXACT, bool SPLIT = true, typename ObsAt>
 __device__ __forceinline__ void obstacle_loop(const ObsConsts& oc, int M, ObsAt obs, StepSums& a) {
   using Prep = ObsPrep;
+  StepSums b{0.0, 0.0, 0.0, 0.0, 0.0};  // SPLIT: the odd entries' sums
   auto prep = [&](const ObsEntry& e, Prep& p) { obs_prep(oc, e, p); };
   // the wave-wide vote of CULL: false when the entry is negligible at every step of the wavefront
   auto wanted = [&](const Prep& p) { return __builtin_amdgcn_ballot_w64(obs_needed(p)) != 0; };
-  auto finish = [&](const ObsEntry& e, const Prep& p, double w) {
+  auto finish = [&](const ObsEntry& e, const Prep& p, double w, bool odd) {
     if (CULL && LANE_EXACT) w = obs_needed(p) ? w : 0.0;
-    obs_accumulate(a, obs_terms(oc, e, p), w);
+    obs_accumulate(SPLIT && odd ? b : a, obs_terms(oc, e, p), w);
   };
   if (CULL && PAIRED) {
     // Entries in PAIRS: the geometry of both first — two independent dependency chains that interleave (a lone wavefront issues a
@@ -614,8 +728,8 @@ __device__ __forceinline__ void obstacle_loop(const ObsConsts& oc, int M, ObsAt 
         v3 = m + 3 < M ? obs(m + 3, e3, w3) : false;
         if (any) {
           const bool na = v0 && wanted(pa), nb = v1 && wanted(pb);
-          if (na) finish(e0, pa, w0);
-          if (nb) finish(e1, pb, w1);
+          if (na) finish(e0, pa, w0, false);
+          if (nb) finish(e1, pb, w1, true);
         }
       }
       if (m + 2 >= M) break;
@@ -627,18 +741,18 @@ __device__ __forceinline__ void obstacle_loop(const ObsConsts& oc, int M, ObsAt 
         v1 = m + 5 < M ? obs(m + 5, e1, w1) : false;
         if (any) {
           const bool na = v2 && wanted(pa), nb = v3 && wanted(pb);
-          if (na) finish(e2, pa, w2);
-          if (nb) finish(e3, pb, w3);
+          if (na) finish(e2, pa, w2, false);
+          if (nb) finish(e3, pb, w3, true);
         }
       }
     }
   } else {
-    // two entries in flight, alternating registers: the next entry's loads fly while this one computes
-    auto add_entry = [&](const ObsEntry& e, double w) {
+    // two entries in flight, alternating registers (`ea`: the even entries, `eb`: the odd ones): the next entry's loads fly while this one computes
+    auto add_entry = [&](const ObsEntry& e, double w, bool odd) {
       Prep p;
       prep(e, p);
       if (CULL && !wanted(p)) return;
-      finish(e, p, w);
+      finish(e, p, w, odd);
     };
     ObsEntry ea, eb;
     double wa = 0.0, wb = 0.0;
@@ -647,13 +761,15 @@ __device__ __forceinline__ void obstacle_loop(const ObsConsts& oc, int M, ObsAt 
     int m = 0;
     for (; m + 1 < M; m += 2) {
       vb = obs(m + 1, eb, wb);
-      if (va) add_entry(ea, wa);
+      if (va) add_entry(ea, wa, false);
       if (m + 2 < M) va = obs(m + 2, ea, wa);
-      if (vb) add_entry(eb, wb);
+      if (vb) add_entry(eb, wb, true);
     }
-    if (m < M && va) add_entry(ea, wa);
+    if (m < M && va) add_entry(ea, wa, false);
   }
-
+  if (SPLIT) {
+    a.lx0 += b.lx0; a.lx1 += b.lx1; a.h00 += b.h00; a.h01 += b.h01; a.h11 += b.h11;
+  }
 }
 
 // Constraints::get_state_cost / get_control_cost for one step (I/Constraints.cpp:145-227, 86-137; obstacles
@@ -675,7 +791,7 @@ __device__ __forceinline__ void obstacle_loop(const ObsConsts& oc, int M, ObsAt 
 // PAIRED (with CULL): entries are taken two at a time with four entries' loads in flight — for obstacle tables streamed from
 // global memory, where it is worth 12 % (config 3 materialised: 7.6 → 6.6 ms); where the entries come from LDS the extra live
 // registers cost more than the overlap brings (config 2 +2.4 %, config 3 compact +2 %), so it is off there.
-template <bool CULL = false, bool PAIRED = false, bool LANE_EXACT = false, typename ObsAt>
+template <bool CULL = false, bool PAIRED = false, bool LANE_EXACT = false, bool SPLIT = !PAIRED, typename ObsAt>
 __device__ __forceinline__ double lin_step(const KParams& kp, double px, double py, double v, double ct, double st, double u0,
                                            double u1, double vn, double cn, double sn, double cx, double cy, int M, ObsAt obs,
                                            Rec& r) {
@@ -686,7 +802,9 @@ __device__ __forceinline__ double lin_step(const KParams& kp, double px, double 
 
   // --- obstacles (I/Constraints.cpp:177-187, I/Obstacle.cpp:39-112): summed from zero, joined with the tracking terms below
   StepSums a{0.0, 0.0, 0.0, 0.0, 0.0};
-  obstacle_loop<CULL, PAIRED, LANE_EXACT>(make_obs_consts(kp, px, py, ct, st), M, obs, a);
+  // (SPLIT: obstacle_loop; one chain where the entries are taken in pairs from a streamed table and in the kernels that deal a step's
+  // entries to several wavefronts by obstacle — those instantiations have no registers left for a second set of sums)
+  obstacle_loop<CULL, PAIRED, LANE_EXACT, SPLIT>(make_obs_consts(kp, px, py, ct, st), M, obs, a);
 
   // --- control cost (I/Constraints.cpp:110-131)
   double a1, a2, a3, a4;

@@ -68,7 +68,7 @@ struct SolveArgs {
   uint32_t flags;
   // The batch has at most one solve per SIMD — the launcher may give every solve a second wavefront (cilqr_solve.hip).
   // 1: cilqr_solve_pair_kernel (the next linearisation runs behind the forward pass instead of after it; an experiment);
-  // 2: cilqr_solve_share_kernel (both wavefronts work on phase L at the same time; the default)
+  // 2, 3: cilqr_solve_share_kernel with that many wavefronts (all of them work on phase L at the same time; the default)
   int32_t pair;
   // grouped family: 1 = in phase L the lanes of a wavefront's finished solves take steps of the unfinished ones (cilqr_solve_groups.hip)
   int32_t steal;

@@ -84,6 +84,22 @@ __device__ __forceinline__ double wave_max_uniform(double v) {  // the same sche
   return fmax(fmax(readlane_any_f64(v, 0), readlane_any_f64(v, 16)), fmax(readlane_any_f64(v, 32), readlane_any_f64(v, 48)));
 }
 
+// closest_sample's Newton search (cilqr_device.hpp) needs the polynomial's coefficients — into LDS, slots CST_PC … + 5 of `cst`, which
+// riccati_mfma's constants leave free — and an upper bound of its second derivative over the samples (returned; wave-uniform).
+constexpr int CST_PC = 6;
+__device__ __forceinline__ double path_curvature_wave(const SampleGrid& grid, const double* pc, int S, int lane, double* cst) {
+  double A = 0.0, B = 0.0;
+  for (int q = lane; q < S; q += WAVE) {
+    double a2, a3;
+    path_curvature_terms(pc, fma(grid.dxs, (double)q, grid.xf), a2, a3);
+    A = fmax(A, a2 == a2 ? a2 : __builtin_huge_val());
+    B = fmax(B, a3 == a3 ? a3 : __builtin_huge_val());
+  }
+  A = wave_max_uniform(A);
+  B = wave_max_uniform(B);
+  if (lane < CILQR_POLY_COEFFS) cst[CST_PC + lane] = pc[lane];
+  return path_curvature_bound(grid, pc, S, A, B);
+}
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, WAVE));
@@ -109,6 +125,21 @@ struct TabObstacles {  // obstacle accessor over the [m][t][field] table (LDS or
   // An entry is 48 contiguous bytes, read as three 16-byte accesses.  In LDS the lane stride of 12 dwords makes each
   // quarter-wave's b128 reads cover all 64 banks exactly once (12·i mod 64, i < 16, are 16 distinct multiples of 4).
   __device__ __forceinline__ bool operator()(int m, ObsEntry& e, double& w) const {
+    const double2* p = reinterpret_cast<const double2*>(tab + (size_t)m * TABF * N);
+    const double2 a = p[0], b = p[1], c = p[2];
+    e.ox = a.x; e.oy = a.y; e.co = b.x; e.so = b.y; e.ia2 = c.x; e.ib2 = c.y;
+    w = wts ? wts[m] : w_default;
+    return true;
+  }
+};
+
+struct TabObstaclesStrided {  // the same over the entries first, first + stride, … (a wavefront's share: cilqr_solve_share_kernel)
+  const double* tab;
+  const double* wts;
+  int N, first, stride;
+  double w_default;
+  __device__ __forceinline__ bool operator()(int j, ObsEntry& e, double& w) const {
+    const int m = first + j * stride;
     const double2* p = reinterpret_cast<const double2*>(tab + (size_t)m * TABF * N);
     const double2 a = p[0], b = p[1], c = p[2];
     e.ox = a.x; e.oy = a.y; e.co = b.x; e.so = b.y; e.ia2 = c.x; e.ib2 = c.y;
@@ -337,7 +368,7 @@ __device__ __forceinline__ double linearize(const KParams& kp, int N, int M, int
       q[1] = make_double2(xr[2], xr[3]);
       q[2] = make_double2(U[2 * t], U[2 * t + 1]);
     }
-    const int cs = closest_sample(S, grid, px, py, LdsSamples{samp, grid.xf, grid.dxs});
+    const int cs = closest_sample<false>(S, grid, px, py, LdsSamples{samp, grid.xf, grid.dxs});
     CILQR_SUB(1, (double)cs)
     Rec c;
     Jpart += lin_step<true, Source::kPaired, FSMEM>(kp, px, py, xr[2], xr[4], xr[5], U[2 * t], U[2 * t + 1], xn[2], xn[4], xn[5], fma(grid.dxs, (double)cs, grid.xf),
@@ -374,7 +405,7 @@ __device__ __forceinline__ double cost_only(const KParams& kp, int N, int lane, 
   double Jpart = 0.0;
   for (int t = lane; t < N; t += WAVE) {
     const double* xr = X + t * XR;
-    const int cs = closest_sample(S, grid, xr[0], xr[1], LdsSamples{samp, grid.xf, grid.dxs});
+    const int cs = closest_sample<false>(S, grid, xr[0], xr[1], LdsSamples{samp, grid.xf, grid.dxs});
     Jpart += stage_cost(kp, xr[0] - fma(grid.dxs, (double)cs, grid.xf), xr[1] - samp[cs], xr[2] - kp.desired_speed, U[2 * t], U[2 * t + 1]);
   }
   return Jpart;
@@ -1150,7 +1181,7 @@ __device__ __forceinline__ bool linearize_quads(const KParams& kp, int N, int M,
     const double cx = fma(grid.dxs, (double)best, grid.xf), cy = samp[best];
     // tracking cost, as lin_step forms it
     const double dx = px - cx, dy = py - cy, dv = v - kp.desired_speed;
-    StepSums a{0.0, 0.0, 0.0, 0.0, 0.0};
+    StepSums a{0.0, 0.0, 0.0, 0.0, 0.0}, ao{0.0, 0.0, 0.0, 0.0, 0.0};  // even / odd entries (obstacle_loop's SPLIT order)
     Rec c;
     c.lx2 = (2 * kp.w_vel) * dv;
     const double J = stage_cost(kp, dx, dy, dv, u0, u1);
@@ -1169,14 +1200,15 @@ __device__ __forceinline__ bool linearize_quads(const KParams& kp, int N, int M,
       if (__builtin_amdgcn_ballot_w64(need) != 0) g = obs_terms(oc, e, p);
       const double we = need ? w : 0.0;  // (lin_step<…, LANE_EXACT>: a step that does not need the entry adds exactly nothing)
       obs_accumulate(a, ObsTerms{quad_bcast<0>(g.gx), quad_bcast<0>(g.gy), quad_bcast<0>(g.gxx), quad_bcast<0>(g.gxy), quad_bcast<0>(g.gyy)}, quad_bcast<0>(we));
-      if (m0 + 1 < M) obs_accumulate(a, ObsTerms{quad_bcast<1>(g.gx), quad_bcast<1>(g.gy), quad_bcast<1>(g.gxx), quad_bcast<1>(g.gxy), quad_bcast<1>(g.gyy)}, quad_bcast<1>(we));
+      if (m0 + 1 < M) obs_accumulate(ao, ObsTerms{quad_bcast<1>(g.gx), quad_bcast<1>(g.gy), quad_bcast<1>(g.gxx), quad_bcast<1>(g.gxy), quad_bcast<1>(g.gyy)}, quad_bcast<1>(we));
       if (m0 + 2 < M) obs_accumulate(a, ObsTerms{quad_bcast<2>(g.gx), quad_bcast<2>(g.gy), quad_bcast<2>(g.gxx), quad_bcast<2>(g.gxy), quad_bcast<2>(g.gyy)}, quad_bcast<2>(we));
-      if (m0 + 3 < M) obs_accumulate(a, ObsTerms{quad_bcast<3>(g.gx), quad_bcast<3>(g.gy), quad_bcast<3>(g.gxx), quad_bcast<3>(g.gxy), quad_bcast<3>(g.gyy)}, quad_bcast<3>(we));
+      if (m0 + 3 < M) obs_accumulate(ao, ObsTerms{quad_bcast<3>(g.gx), quad_bcast<3>(g.gy), quad_bcast<3>(g.gxx), quad_bcast<3>(g.gxy), quad_bcast<3>(g.gyy)}, quad_bcast<3>(we));
     }
     // control cost: one of its four exponentials per lane of the quad
     double a1, a2, a3, a4;
     ctrl_args(kp, u0, u1, v, a1, a2, a3, a4);
     const double ee = exp_fast(sub == 0 ? a1 : sub == 1 ? a2 : sub == 2 ? a3 : a4);
+    a.lx0 += ao.lx0; a.lx1 += ao.lx1; a.h00 += ao.h00; a.h01 += ao.h01; a.h11 += ao.h11;
     state_terms(kp, dx, dy, a, c.lx0, c.lx1, c.l00, c.l01, c.l11);
     ctrl_terms(kp, u0, u1, quad_bcast<0>(ee), quad_bcast<1>(ee), quad_bcast<2>(ee), quad_bcast<3>(ee), c);
     ab_terms(kp, u0, vn, cn, sn, c);
@@ -1463,7 +1495,7 @@ __global__ __launch_bounds__(W * WAVE, 2) void cilqr_solve_split_kernel(SolveArg
                           sqrt(1.0 + 64.0 / kpl.q2_front), sqrt(1.0 + 64.0 / kpl.q2_rear)};
         src.o_first = wave; src.o_stride = W;
         StepSums s5{0.0, 0.0, 0.0, 0.0, 0.0};
-        obstacle_loop<true, false, false>(make_obs_consts(kpl, xr[0], xr[1], xr[4], xr[5]), n_mine * NSMP, src.at(t), s5);
+        obstacle_loop<true, false, false, false>(make_obs_consts(kpl, xr[0], xr[1], xr[4], xr[5]), n_mine * NSMP, src.at(t), s5);
         double* q = part + ((size_t)(wave - 1) * N + t) * 5;
         q[0] = s5.lx0; q[1] = s5.lx1; q[2] = s5.h00; q[3] = s5.h01; q[4] = s5.h11;
       }
@@ -1488,11 +1520,11 @@ __global__ __launch_bounds__(W * WAVE, 2) void cilqr_solve_split_kernel(SolveArg
       if (act) {
         const double* xr = Xa + t * XR;
         const double* xn = Xa + (t + 1) * XR;
-        const int cs = closest_sample(S, grid, xr[0], xr[1], LdsSamples{samp, grid.xf, grid.dxs});
+        const int cs = closest_sample<false>(S, grid, xr[0], xr[1], LdsSamples{samp, grid.xf, grid.dxs});
         SampledSource src{tab, off, rmax, Xa, N, NSMP, M, a.samp_w, kpl.ego_front, kpl.ego_rear,
                           sqrt(1.0 + 64.0 / kpl.q2_front), sqrt(1.0 + 64.0 / kpl.q2_rear)};
         src.o_first = 0; src.o_stride = W;
-        Jt = lin_step<true, false, false>(kpl, xr[0], xr[1], xr[2], xr[4], xr[5], Ua[2 * t], Ua[2 * t + 1], xn[2], xn[4], xn[5],
+        Jt = lin_step<true, false, false, false>(kpl, xr[0], xr[1], xr[2], xr[4], xr[5], Ua[2 * t], Ua[2 * t + 1], xn[2], xn[4], xn[5],
                                            fma(grid.dxs, (double)cs, grid.xf), samp[cs], n_mine * NSMP, src.at(t), c);
       }
       __syncthreads();  // A
@@ -1586,7 +1618,7 @@ __global__ __launch_bounds__(W * WAVE, 2) void cilqr_solve_split_kernel(SolveArg
 #undef CILQR_STAMP
 }
 
-// ==== Static obstacles, two wavefronts per solve that share phase L (BASELINE config 2's shape, up to one solve per SIMD) ===========
+// ==== Static obstacles, two or three wavefronts per solve that share phase L (BASELINE config 2's shape, up to two solves per SIMD) ====
 // A batch of at most one solve per SIMD ends when its LONGEST solve does (config 2: 13 of 1024 solves run all 20 passes, the mean
 // solve 7.8), so what counts is the length of one pass — R + F + L = 18.6 k + 17.8 k + 8.3 k ticks at N = 50, M = 4 — and R and F
 // are serial chains at the issue rate of a lone wavefront.  Phase L is not one chain: the closest-sample search with the tracking
@@ -1603,13 +1635,17 @@ __global__ __launch_bounds__(W * WAVE, 2) void cilqr_solve_split_kernel(SolveArg
 // two meet at two barriers per pass.  While every SIMD still holds a main wavefront the aux wavefronts take issue slots from the
 // main wavefronts of OTHER solves (work-conserving: no gain, no loss to speak of); once the short solves have ended — the larger
 // part of the launch — the long ones have their SIMDs' partners to themselves and a pass is ≈ 4.5 k ticks shorter.
+// W = 3 (up to one solve per SIMD): the obstacle terms are split once more — wavefront 1 sums the entries of EVEN index, wavefront 2
+// those of odd index, each in one chain, in order, which is obstacle_loop's own order of summation (cilqr_device.hpp, SPLIT); wavefront
+// 2 also takes the Jacobian slots and the control barrier, and main adds odd sums to even sums as obstacle_loop does.  The solves that
+// decide a launch are the ones with every obstacle close (their aux wavefront took 6.1 k ticks per call where the mean took 4.3 k).
 // Bits: the statements are lin_step's, piece by piece (cilqr_device.hpp: obstacle sums from zero, state_terms), so a record does
 // not depend on which wavefront formed which slot — results are bit-identical to cilqr_solve_kernel's (tests/test_gpu_parity.py,
 // test_share_kernel_changes_no_bit).  Horizons up to 63 (one state per lane), obstacle table in LDS, no map, early-exit mode.
 // DIAG: a.diag[b] = {prologue, L (main's share + the wait at barrier A + the combine), R, F, epilogue, #L, #R, total, aux: busy
 // ticks, aux: calls, main: ticks waiting at barrier A, 0…}.
-template <bool DIAG>
-__global__ __launch_bounds__(2 * WAVE, 2) void cilqr_solve_share_kernel(SolveArgs a) {  // (two wavefronts per SIMD: ≤ 256 vector registers)
+template <int W, bool DIAG>
+__global__ __launch_bounds__(W * WAVE, W) void cilqr_solve_share_kernel(SolveArgs a) {  // (W wavefronts per SIMD: ≤ 256 / 168 vector registers)
   unsigned long long tk0 = 0, tk = 0, c_pro = 0, c_L = 0, c_R = 0, c_F = 0, n_L = 0, n_R = 0, c_wait = 0;
   if (DIAG) tk0 = tk = __builtin_readcyclecounter();
 #define CILQR_STAMP(acc)                                 \
@@ -1632,8 +1668,8 @@ __global__ __launch_bounds__(2 * WAVE, 2) void cilqr_solve_share_kernel(SolveArg
   double* rec = Ua + 2 * N;
   double* cst = rec + N * RECF;
   double* tab = cst + RCST;
-  double* part = tab + (size_t)M * TABF * N;  // [N][5]: the aux wavefront's sums of a step's obstacle terms
-  double* ctl = part + ((5 * N + 1) & ~1);
+  double* part = tab + (size_t)M * TABF * N;  // [W - 1][N][5]: the aux wavefronts' sums of a step's obstacle terms
+  double* ctl = part + (((W - 1) * 5 * N + 1) & ~1);  // {command word, dmax, curvature bound, -}
   int* const cmd = reinterpret_cast<int*>(ctl);
   double* fwd = a.fwd + (size_t)b * (N + 1) * FREC;
 
@@ -1642,7 +1678,7 @@ __global__ __launch_bounds__(2 * WAVE, 2) void cilqr_solve_share_kernel(SolveArg
   SampleGrid grid;
   make_sample_grid(grid, a.xplan_fl[2 * b], a.xplan_fl[2 * b + 1], S);
   const double* Ug = a.U + (size_t)b * 2 * N;
-  for (int i = tid; i < 2 * N; i += 2 * WAVE) Ua[i] = Ug[i];
+  for (int i = tid; i < 2 * N; i += W * WAVE) Ua[i] = Ug[i];
   if (tid < 16 && (tid & 7) < 5) cst[(tid & 7) + (tid >> 3) * RECF] = (tid & 7) == 0 ? 0.0 : (tid & 7) == 1 ? 1.0 : (tid & 7) == 2 ? kp.dt : (tid & 7) == 3 ? kp.w_vel * 2 : 2.0;
   if (tid == 0) cmd[0] = 0;
   const double* wts = a.obs_weight ? a.obs_weight + (size_t)b * M : nullptr;
@@ -1652,28 +1688,35 @@ __global__ __launch_bounds__(2 * WAVE, 2) void cilqr_solve_share_kernel(SolveArg
     handover = !rollout_fast(kp, N, a.x0 + (size_t)b * 4, Ua, Xa);  // nominal rollout, I/iLQR.cpp:51-62
     if (handover && lane == 0) *reinterpret_cast<volatile int*>(cmd) = CMD_EXIT;
   } else {
-    const double* pc = a.poly + (size_t)b * CILQR_POLY_COEFFS;
-    for (int s = lane; s < S; s += WAVE) {
-      double xs;
-      sample_xy(grid, pc, s, xs, samp[s]);
-    }
-    for (int i = lane; i < M * N; i += WAVE) {  // obstacle table, I/Obstacle.cpp:41-62 (entry i = m·N + t, as the inputs lie)
+    // (W = 3: the two aux wavefronts share the table; samples and their largest step on the first)
+    const int al = lane + (wave - 1) * WAVE, an = (W - 1) * WAVE;
+    for (int i = al; i < M * N; i += an) {  // obstacle table, I/Obstacle.cpp:41-62 (entry i = m·N + t, as the inputs lie)
       const ObsEntry e = make_obs_entry(kp, a.obs_pose + ((size_t)b * M * N + i) * 4, a.obs_dim + ((size_t)b * M * N + i) * 2);
       double* o = tab + (size_t)i * TABF;
       o[0] = e.ox; o[1] = e.oy; o[2] = e.co; o[3] = e.so; o[4] = e.ia2; o[5] = e.ib2;
     }
-    // largest step between adjacent path samples in y: closest_sample's second window (cilqr_device.hpp); to the main wavefront through LDS
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the samples: written above by lanes of this wavefront)
-    double m = 0.0;
-    for (int q = lane; q + 1 < S; q += WAVE) {
-      const double d = fabs(samp[q + 1] - samp[q]);
-      m = fmax(m, d == d ? d : __builtin_huge_val());
+    if (wave == 1) {
+      const double* pc = a.poly + (size_t)b * CILQR_POLY_COEFFS;
+      for (int s = lane; s < S; s += WAVE) {
+        double xs;
+        sample_xy(grid, pc, s, xs, samp[s]);
+      }
+      // largest step between adjacent path samples in y: closest_sample's second window (cilqr_device.hpp); to the main wavefront through LDS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the samples: written above by lanes of this wavefront)
+      double m = 0.0;
+      for (int q = lane; q + 1 < S; q += WAVE) {
+        const double d = fabs(samp[q + 1] - samp[q]);
+        m = fmax(m, d == d ? d : __builtin_huge_val());
+      }
+      m = wave_max_uniform(m);
+      const double p2 = path_curvature_wave(grid, pc, S, lane, cst);  // (and the coefficients into LDS: closest_sample's Newton search)
+      if (lane == 0) { ctl[1] = m; ctl[2] = p2; }
     }
-    m = wave_max_uniform(m);
-    if (lane == 0) ctl[1] = m;
   }
   __syncthreads();  // trajectory, samples and table are in LDS
   grid.dmax = ctl[1];
+  grid.p2 = ctl[2];
+  grid.pc = cst + CST_PC;
 
   const int t = lane;
   const bool act = t < N;
@@ -1690,24 +1733,44 @@ __global__ __launch_bounds__(2 * WAVE, 2) void cilqr_solve_share_kernel(SolveArg
       const double cn = __shfl_down(cA, 1, WAVE), sn = __shfl_down(sA, 1, WAVE);
       if (act) {
         const double* xr = Xa + t * XR;
-        const double u0 = Ua[2 * t];
+        const double u0 = Ua[2 * t], u1 = Ua[2 * t + 1];
         StepSums s5{0.0, 0.0, 0.0, 0.0, 0.0};
-        obstacle_loop<true, false, true>(make_obs_consts(kpl, xr[0], xr[1], cA, sA), M, TabSource<false>{tab, wts, N, kpl.w_obstacle}.at(t), s5);
-        double* q = part + (size_t)t * 5;
+        const ObsConsts oc = make_obs_consts(kpl, xr[0], xr[1], cA, sA);
+        if (W == 2) {  // every entry: even and odd chains, as lin_step forms them
+          obstacle_loop<true, false, true>(oc, M, TabSource<false>{tab, wts, N, kpl.w_obstacle}.at(t), s5);
+        } else {       // this wavefront's chain: entries wave - 1, wave + 1, …
+          const int first = wave - 1;
+          obstacle_loop<true, false, true, false>(oc, (M - first + 1) / 2, TabObstaclesStrided{tab + (size_t)t * TABF, wts, N, first, 2, kpl.w_obstacle}, s5);
+        }
+        double* q = part + ((size_t)(wave - 1) * N + t) * 5;
         q[0] = s5.lx0; q[1] = s5.lx1; q[2] = s5.h00; q[3] = s5.h01; q[4] = s5.h11;
-        Rec c;
-        ab_terms(kpl, u0, Xa[(t + 1) * XR + 2], cn, sn, c);
-        double* r = rec + t * RECF;
-        r[10] = c.al; r[11] = c.be; r[12] = c.ga; r[13] = c.de;
+        if (wave == W - 1) {  // the last aux wavefront: Jacobians, and with W = 3 the control barrier (with W = 2: on main)
+          Rec c;
+          ab_terms(kpl, u0, Xa[(t + 1) * XR + 2], cn, sn, c);
+          double* r = rec + t * RECF;
+          r[10] = c.al; r[11] = c.be; r[12] = c.ga; r[13] = c.de;
+          if (W == 3) {
+            double a1, a2, a3, a4;
+            ctrl_args(kpl, u0, u1, xr[2], a1, a2, a3, a4);
+            const double e1 = exp_fast(a1);
+            const double e2 = exp_fast(a2);
+            const double e3 = exp_fast(a3);
+            const double e4 = exp_fast(a4);
+            ctrl_terms(kpl, u0, u1, e1, e2, e3, e4, c);
+            const double ih = 2.0 / kpl.dt;  // production records: acceleration in units of (dt/2)·u0 (riccati_mfma)
+            r[6] = c.lu0 * ih; r[7] = c.lu1; r[8] = c.luu0 * (ih * ih); r[9] = c.luu1;
+          }
+        }
       }
       if (DIAG) { busy += stamp_after(cn) - t0; ++calls; }
       __syncthreads();  // A: sums and record slots are in LDS
       __syncthreads();  // B: main has decided, and, going on, has written the next trajectory
     }
-    if (DIAG && lane == 0 && a.diag) {
+    if (DIAG && lane == 0 && a.diag && wave == 1) {
       unsigned long long* o = a.diag + (size_t)b * DIAG_SLOTS;
       o[8] = busy; o[9] = calls;
     }
+    if (DIAG && lane == 0 && a.diag && wave == 2) a.diag[(size_t)b * DIAG_SLOTS + 11] = busy;
     return;
   }
 
@@ -1736,17 +1799,19 @@ __global__ __launch_bounds__(2 * WAVE, 2) void cilqr_solve_share_kernel(SolveArg
         const double dv = v - kpl.desired_speed;
         lx2 = (2 * kpl.w_vel) * dv;
         Jt = stage_cost(kpl, dx, dy, dv, u0, u1);
-        Rec c;  // control barrier (I/Constraints.cpp:110-131)
-        double a1, a2, a3, a4;
-        ctrl_args(kpl, u0, u1, v, a1, a2, a3, a4);
-        const double e1 = exp_fast(a1);
-        const double e2 = exp_fast(a2);
-        const double e3 = exp_fast(a3);
-        const double e4 = exp_fast(a4);
-        ctrl_terms(kpl, u0, u1, e1, e2, e3, e4, c);
-        double* r = rec + t * RECF;
-        const double ih = 2.0 / kpl.dt;  // production records: acceleration in units of (dt/2)·u0 (riccati_mfma)
-        r[6] = c.lu0 * ih; r[7] = c.lu1; r[8] = c.luu0 * (ih * ih); r[9] = c.luu1;
+        if (W == 2) {  // control barrier (I/Constraints.cpp:110-131); with three wavefronts: on the last one
+          Rec c;
+          double a1, a2, a3, a4;
+          ctrl_args(kpl, u0, u1, v, a1, a2, a3, a4);
+          const double e1 = exp_fast(a1);
+          const double e2 = exp_fast(a2);
+          const double e3 = exp_fast(a3);
+          const double e4 = exp_fast(a4);
+          ctrl_terms(kpl, u0, u1, e1, e2, e3, e4, c);
+          double* r = rec + t * RECF;
+          const double ih = 2.0 / kpl.dt;  // production records: acceleration in units of (dt/2)·u0 (riccati_mfma)
+          r[6] = c.lu0 * ih; r[7] = c.lu1; r[8] = c.luu0 * (ih * ih); r[9] = c.luu1;
+        }
       }
       J_new = wave_sum_uniform(Jt);
       unsigned long long w0 = 0;
@@ -1755,7 +1820,11 @@ __global__ __launch_bounds__(2 * WAVE, 2) void cilqr_solve_share_kernel(SolveArg
       if (DIAG) c_wait += __builtin_readcyclecounter() - w0;
       if (act) {
         const double* q = part + (size_t)t * 5;
-        const StepSums s5{q[0], q[1], q[2], q[3], q[4]};
+        StepSums s5{q[0], q[1], q[2], q[3], q[4]};
+        if (W == 3) {  // odd sums onto even sums: obstacle_loop's last statement
+          const double* qo = q + (size_t)N * 5;
+          s5.lx0 += qo[0]; s5.lx1 += qo[1]; s5.h00 += qo[2]; s5.h01 += qo[3]; s5.h11 += qo[4];
+        }
         double* r = rec + t * RECF;
         double lx0, lx1, l00, l01, l11;
         state_terms(kpl, dx, dy, s5, lx0, lx1, l00, l01, l11);
@@ -1834,7 +1903,8 @@ __global__ __launch_bounds__(2 * WAVE, 2) void cilqr_solve_share_kernel(SolveArg
     unsigned long long* o = a.diag + (size_t)b * DIAG_SLOTS;
     o[0] = c_pro; o[1] = c_L; o[2] = c_R; o[3] = c_F; o[4] = now_ - tk; o[5] = n_L; o[6] = n_R; o[7] = now_ - tk0;
     o[10] = c_wait;
-    for (int q = 11; q < DIAG_SLOTS; ++q) o[q] = 0;
+    for (int q = 12; q < DIAG_SLOTS; ++q) o[q] = 0;
+    if (W == 2) o[11] = 0;
   }
 #undef CILQR_STAMP
 }
@@ -1902,11 +1972,11 @@ hipError_t launch_two_wavefronts(const SolveArgs& a, size_t tab_bytes, hipStream
   return hipGetLastError();
 }
 // The shared-phase-L kernel (table in LDS, no map, early exit, N ≤ 63) with the GENERAL kernel of the one-wavefront family behind it.
-template <bool DIAG>
+template <int W, bool DIAG>
 hipError_t launch_shared_L(const SolveArgs& a, size_t tab_bytes, hipStream_t stream) {
-  const size_t lds_fast = core_lds_bytes(a.N, a.kp.n_samples, true) + tab_bytes + ((((size_t)5 * a.N + 1) & ~(size_t)1) + 2) * sizeof(double);
+  const size_t lds_fast = core_lds_bytes(a.N, a.kp.n_samples, true) + tab_bytes + ((((size_t)(W - 1) * 5 * a.N + 1) & ~(size_t)1) + 4) * sizeof(double);
   const size_t lds_general = core_lds_bytes(a.N, a.kp.n_samples, false) + tab_bytes;
-  hipLaunchKernelGGL((cilqr_solve_share_kernel<DIAG>), dim3(a.B), dim3(2 * WAVE), lds_fast, stream, a);
+  hipLaunchKernelGGL((cilqr_solve_share_kernel<W, DIAG>), dim3(a.B), dim3(W * WAVE), lds_fast, stream, a);
   hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, 1, true, false>), dim3(a.B), dim3(WAVE), lds_general, stream, a);
   return hipGetLastError();
 }
@@ -2001,8 +2071,10 @@ hipError_t launch_solve_wave(const SolveArgs& a, hipStream_t stream) {
   const size_t extra = tab_lds ? tab_bytes : 0;
   if (tab_lds && a.pair == 1 && !a.unc.layer && (a.flags & CILQR_FLAG_FAITHFUL_ITERS) == 0)
     return a.diag ? launch_two_wavefronts<true>(a, tab_bytes, stream) : launch_two_wavefronts<false>(a, tab_bytes, stream);
-  if (a.pair == 2 && a.n_samples == 0 && solve_share_applies(a.N, a.M, a.kp.n_samples) && !a.unc.layer && (a.flags & CILQR_FLAG_FAITHFUL_ITERS) == 0)
-    return a.diag ? launch_shared_L<true>(a, tab_bytes, stream) : launch_shared_L<false>(a, tab_bytes, stream);
+  if (a.pair >= 2 && a.n_samples == 0 && solve_share_applies(a.N, a.M, a.kp.n_samples) && !a.unc.layer && (a.flags & CILQR_FLAG_FAITHFUL_ITERS) == 0) {
+    if (a.pair == 3 && a.M >= 2) return a.diag ? launch_shared_L<3, true>(a, tab_bytes, stream) : launch_shared_L<3, false>(a, tab_bytes, stream);
+    return a.diag ? launch_shared_L<2, true>(a, tab_bytes, stream) : launch_shared_L<2, false>(a, tab_bytes, stream);
+  }
   if (a.diag) return tab_lds ? launch_pair<true, 1>(a, extra, stream) : launch_pair<true, 0>(a, extra, stream);
   return tab_lds ? launch_pair<false, 1>(a, extra, stream) : launch_pair<false, 0>(a, extra, stream);
 }

@@ -73,7 +73,7 @@ extern __shared__ __attribute__((aligned(16))) double cilqr_groups_lds[];
 constexpr int F_ROWS = XR + 2 + KR;  // forward pass: 6 state + 2 control + 10 gain rows per step
 // Per-solve block in LDS (phase L's lane sharing): {poly[6], xf, dxs, inv_dxs, dmax, windowed, held mask, map pose[4], xc | uc}
 constexpr int PAR = 18;
-constexpr int P_XF = 6, P_DXS = 7, P_INV = 8, P_DMAX = 9, P_WIN = 10, P_HELD = 11, P_POSE = 12, P_BUF = 16;
+constexpr int P_XF = 6, P_DXS = 7, P_INV = 8, P_DMAX = 9, P_WIN = 10, P_HELD = 11, P_POSE = 12, P_BUF = 16, P_P2 = 17;
 
 // n_doubles (even) contiguous doubles from src (global, wave-uniform) to dst (LDS, wave-uniform) by the asynchronous
 // direct-to-LDS load: 16 bytes per lane and instruction, no data registers.  Called only where the wavefront is whole (see the
@@ -161,6 +161,22 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_fast(SolveArgs a, dou
       for (int o = G / 2; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, WAVE));
       grid.dmax = m;
     }
+    {  // an upper bound of the path's second derivative over the samples: closest_sample's Newton search (cilqr_device.hpp)
+      double A = 0.0, Bq = 0.0;
+      for (int q = g; q < NS; q += G) {
+        double a2, a3;
+        path_curvature_terms(pc, fma(grid.dxs, (double)q, grid.xf), a2, a3);
+        A = fmax(A, a2 == a2 ? a2 : __builtin_huge_val());
+        Bq = fmax(Bq, a3 == a3 ? a3 : __builtin_huge_val());
+      }
+#pragma unroll
+      for (int o = G / 2; o > 0; o >>= 1) {
+        A = fmax(A, __shfl_xor(A, o, WAVE));
+        Bq = fmax(Bq, __shfl_xor(Bq, o, WAVE));
+      }
+      grid.p2 = path_curvature_bound(grid, pc, NS, A, Bq);
+      grid.pc = pc;
+    }
     double* Ug = a.U + (size_t)b * 2 * N;
     for (int t = g; t < N; t += G) {
       UF(L.ua(), t, 0) = Ug[2 * t];
@@ -199,7 +215,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_fast(SolveArgs a, dou
     double* q = par + (size_t)grp * PAR;
 #pragma unroll
     for (int j = 0; j < CILQR_POLY_COEFFS; ++j) q[j] = pc[j];
-    q[P_XF] = grid.xf; q[P_DXS] = grid.dxs; q[P_INV] = grid.inv_dxs; q[P_DMAX] = grid.dmax; q[P_WIN] = grid.windowed ? 1.0 : 0.0;
+    q[P_XF] = grid.xf; q[P_DXS] = grid.dxs; q[P_INV] = grid.inv_dxs; q[P_DMAX] = grid.dmax; q[P_WIN] = grid.windowed ? 1.0 : 0.0; q[P_P2] = grid.p2;
     reinterpret_cast<unsigned long long*>(q)[P_HELD] = held;
     q[P_POSE] = upose.px; q[P_POSE + 1] = upose.py; q[P_POSE + 2] = upose.cp; q[P_POSE + 3] = upose.sp;
     reinterpret_cast<int*>(q + P_BUF)[0] = L.xa(); reinterpret_cast<int*>(q + P_BUF)[1] = L.ua();
@@ -275,6 +291,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_fast(SolveArgs a, dou
         for (int j = 0; j < CILQR_POLY_COEFFS; ++j) pcs[j] = q[j];
         SampleGrid gs;
         gs.xf = q[P_XF]; gs.dxs = q[P_DXS]; gs.inv_dxs = q[P_INV]; gs.dmax = q[P_DMAX]; gs.windowed = q[P_WIN] != 0.0;
+        gs.p2 = q[P_P2]; gs.pc = pcs;
         const unsigned long long held_s = reinterpret_cast<const unsigned long long*>(q)[P_HELD];
         const int xcs = reinterpret_cast<const int*>(q + P_BUF)[0], ucs = reinterpret_cast<const int*>(q + P_BUF)[1];
         const int bs = blockIdx.x * S + my_slot;
@@ -533,7 +550,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_fast(SolveArgs a, dou
       double Jp = 0.0;
       for (int t = g; t < N; t += G) {
         const double px = XF(xc, t, 0), py = XF(xc, t, 1);
-        const int cs = closest_sample(NS, grid, px, py, sample_at);
+        const int cs = closest_sample<false>(NS, grid, px, py, sample_at);
         double cx, cy;
         sample_xy(grid, pc, cs, cx, cy);
         Jp += stage_cost(ae.kp, px - cx, py - cy, XF(xc, t, 2) - ae.kp.desired_speed, UF(uc, t, 0), UF(uc, t, 1));
@@ -629,7 +646,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_general(SolveArgs a, 
     double Jpart = 0.0;
     for (int t = g; t < N; t += G) {  // phase L
       const double px = XF(xc, t, 0), py = XF(xc, t, 1);
-      const int cs = closest_sample(NS, grid, px, py, sample_at);
+      const int cs = closest_sample<false>(NS, grid, px, py, sample_at);
       double cx, cy;
       sample_xy(grid, pc, cs, cx, cy);
       auto obs = [&](int m, ObsEntry& e, double& w) {
@@ -727,7 +744,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_general(SolveArgs a, 
       double Jp = 0.0;
       for (int t = g; t < N; t += G) {
         const double px = XF(xc, t, 0), py = XF(xc, t, 1);
-        const int cs = closest_sample(NS, grid, px, py, sample_at);
+        const int cs = closest_sample<false>(NS, grid, px, py, sample_at);
         double cx, cy;
         sample_xy(grid, pc, cs, cx, cy);
         Jp += stage_cost(kp, px - cx, py - cy, XF(xc, t, 2) - kp.desired_speed, UF(uc, t, 0), UF(uc, t, 1));
