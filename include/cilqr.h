@@ -385,6 +385,12 @@ int cilqr_solve_sampled_wavefronts(const cilqr_handle* h, int B, int N, int n_ob
  * GENERAL kernel (NaN rows where it reports a non-finite matrix).  Lets the rarely taken branch be checked against the
  * reference's EigenSolver outputs (tests/golden/ref_quu.json) without having to provoke it through a whole solve. */
 int cilqr_debug_quu_inverse(cilqr_handle* h, int n, const double* Quu, const double* lamb, double* Qinv, int general);
+/* Test hook: the kernels' closest-path-sample search (Constraints::find_closest_point, I/Constraints.cpp:24-59: the strict-< first
+ * minimum of the squared distance over all samples; csrc/cilqr_device.hpp::closest_sample finds it from two pruning windows and, where
+ * the window is wide and the distance provably convex over it, by Newton) on n independent queries (host buffers).  queries[i] =
+ * {poly[6], x_local_plan first, last, point x, y}; out[i] = {the search's index, the index a plain scan over ALL samples of the same
+ * kernel finds, 1 if the Newton search decided}.  The two indices must be equal for every query. */
+int cilqr_debug_closest_sample(cilqr_handle* h, int n, const double* queries, int32_t* out);
 
 /* Test hook: the blur kernel's own covariance → confidence-ellipse step (float eigen-solve following Eigen::EigenSolver
  * <Matrix2f>, M/src/arbitrary_transformation.cu:60-83 + M/include/ARBIT.cuh:82-99) on n covariances {a, b, c} (host buffers);

@@ -1182,6 +1182,107 @@ def test_closest_point_windows_on_steep_and_distant_paths(cilqr, oracle, G, monk
     assert (~np.isfinite(got["U"][bad]).all(axis=1) | (got["status"][bad] == cilqr.EXIT_NUMERIC)).all()
 
 
+def test_closest_sample_search_equals_full_scan(cilqr, solver):
+    """`cilqr_debug_closest_sample`: the kernels' closest-sample search (two pruning windows; Newton on the continuous distance where
+    the window is wide and the distance provably convex over it) against a plain scan over all 200 samples in the same kernel, on
+    400 000 random queries: gentle paths as the benchmarks have them, steep and strongly curved ones, cubic and quintic terms, points
+    on the path, far beside it (both sides of the centre of curvature), before and beyond its ends, reversed sample order, exact
+    ties (a straight path with the point midway between two samples).  Every index equal; and the Newton search must really be
+    the one that decides a good share of the wide-window queries (else this test tests the scan against itself)."""
+    rng = np.random.default_rng(9100)
+    n = 400_000
+    q = np.zeros((n, 10))
+    xf = rng.uniform(-5.0, 5.0, n)
+    length = rng.uniform(8.0, 30.0, n) * np.where(rng.random(n) < 0.1, -1.0, 1.0)
+    kind = rng.integers(0, 4, n)
+    slope = np.where(kind == 0, rng.uniform(-0.3, 0.3, n), rng.uniform(-2.0, 2.0, n))
+    curv = np.where(kind == 0, rng.uniform(-0.01, 0.01, n), np.where(kind == 1, 0.0, rng.uniform(-0.2, 0.2, n)))
+    c3 = np.where(kind == 3, rng.uniform(-0.004, 0.004, n), 0.0)
+    c5 = np.where(kind == 3, rng.uniform(-2e-6, 2e-6, n), 0.0)
+    y0 = rng.uniform(-3.0, 3.0, n)
+    # y(u) = y0 + slope u + curv u² + c3 u³ + c5 u⁵, u = x - xf, expanded in powers of x (binomial sums, vectorised)
+    cu = np.stack([y0, slope, curv, c3, np.zeros(n), c5], axis=1)
+    from math import comb
+    for j in range(6):
+        for i in range(j + 1):
+            q[:, i] += cu[:, j] * comb(j, i) * (-xf) ** (j - i)
+    q[:, 6] = xf
+    q[:, 7] = xf + length
+    along = rng.uniform(-0.3, 1.3, n) * length
+    yp = y0 + slope * along + curv * along ** 2 + c3 * along ** 3 + c5 * along ** 5
+    lateral = np.where(rng.random(n) < 0.2, 0.0, rng.uniform(-10.0, 10.0, n))
+    q[:, 8] = xf + along
+    q[:, 9] = yp + lateral
+    # exact ties: a horizontal straight path, the point above the midpoint of two samples (dxs = length / 200, exactly representable)
+    t = np.arange(0, 2000)
+    q[t, :6] = 0.0
+    q[t, 0] = 1.0
+    q[t, 6] = 0.0
+    q[t, 7] = 25.0
+    q[t, 8] = 0.125 * (t % 190) + 0.0625
+    q[t, 9] = 1.0 + rng.uniform(0.0, 7.0, len(t))
+    out = solver.debug_closest_sample(q)
+    bad = np.nonzero(out[:, 0] != out[:, 1])[0]
+    assert bad.size == 0, "search != full scan at %d queries, first: %s -> %s" % (bad.size, q[bad[:1]], out[bad[:1]])
+    share = out[:, 2].mean()
+    print("closest-sample search: Newton decided %.1f %% of %d queries" % (100 * share, n))
+    assert share > 0.15
+
+
+@pytest.mark.parametrize("G", [0, 8])
+def test_closest_point_newton_on_curved_paths(cilqr, oracle, G, monkeypatch):
+    """Wide search windows are resolved by Newton on the continuous distance where it is provably convex over the window
+    (cilqr_device.hpp::closest_newton), by the scan otherwise — the reference's argmin over all 200 samples either way.  Paths with
+    real curvature (second-order coefficient up to ±0.2: radius 2.5 m, egos on both sides of the centre of curvature, where convexity
+    fails and the search must fall back), cubic and quintic terms (the bound of the second derivative is taken over all samples),
+    egos up to 8 m beside the path and beyond its ends — whole solves against the oracle; the shared-phase-L kernel (G = 0) and the
+    grouped family."""
+    from cilqr_amd import scenes
+    if G:
+        monkeypatch.setenv("CILQR_FORCE_G", str(G))
+    N, M, B = 40, 2, 256
+    p = cilqr.default_params(N)
+    sc = scenes.make_static(B, N, M, p, 4342)
+    rng = np.random.default_rng(4343)
+    xf = sc["xplan_fl"][:, 0]
+    slope = rng.uniform(-1.0, 1.0, B)
+    curv = rng.uniform(-0.2, 0.2, B)
+    curv[:64] = rng.uniform(-0.03, 0.03, 64)
+    c3 = rng.uniform(-0.004, 0.004, B)
+    c5 = rng.uniform(-2e-6, 2e-6, B)
+    c3[64:128] = 0.0
+    c5[64:160] = 0.0
+    y0 = rng.uniform(-3, 3, B)
+    # y(u) = y0 + slope u + curv u² + c3 u³ + c5 u⁵ with u = x - xf, expanded in powers of x
+    poly = np.zeros((B, 6))
+    for b in range(B):
+        q = np.polynomial.polynomial.Polynomial([y0[b], slope[b], curv[b], c3[b], 0.0, c5[b]])
+        shifted = q(np.polynomial.polynomial.Polynomial([-xf[b], 1.0]))
+        co = shifted.coef
+        poly[b, :len(co)] = co
+    x0 = sc["x0"].copy()
+    along = rng.uniform(-6.0, 26.0, B)
+    yp = y0 + slope * along + curv * along ** 2 + c3 * along ** 3 + c5 * along ** 5
+    x0[:, 0] = xf + along
+    x0[:, 1] = yp + rng.uniform(-8.0, 8.0, B)
+    x0[:, 3] = np.arctan(slope + 2 * curv * along) + rng.uniform(-0.3, 0.3, B)
+    sc2 = dict(sc, poly=poly, x0=x0)
+    s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M, device=0)
+    try:
+        got = _gpu_batch(s, sc2)
+        if not G:
+            assert s.solve_wavefronts(B, N, M) == 3
+    finally:
+        s.close()
+    want = _oracle_batch(oracle, N, sc2)
+    ok = np.isfinite(want["U"]).all(axis=1)
+    assert ok.sum() >= B * 0.75
+    _compare({k: v[ok] for k, v in got.items()}, {k: v[ok] for k, v in want.items()}, 1e-8, "closest point by Newton G=%d" % G)
+    bad = ~ok
+    assert np.array_equal(got["status"][bad], want["status"][bad])
+    assert np.array_equal(got["iters"][bad], want["iters"][bad])
+
+
 @pytest.mark.parametrize("G", [1, 8, 32])
 def test_early_exit_equals_reference_loop_grouped_family(cilqr, monkeypatch, G):
     """The same equivalence for the G-lanes-per-solve family: stopping at the first rejection and replaying the λ / counter

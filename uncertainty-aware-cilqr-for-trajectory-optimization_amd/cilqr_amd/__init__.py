@@ -20,7 +20,7 @@ EXIT_TOLERANCE, EXIT_LAMBDA_MAX, EXIT_MAX_ITER, EXIT_NUMERIC = 0, 1, 2, 3
 ABI_SYMBOLS = (
     "cilqr_params_default", "cilqr_abi_version", "cilqr_device_count", "cilqr_last_error", "cilqr_default_control_seq",
     "cilqr_local_plan", "cilqr_local_plan_batch", "cilqr_local_plan_batch_device", "cilqr_create", "cilqr_destroy", "cilqr_host_alloc", "cilqr_host_free", "cilqr_solve_batch", "cilqr_solve_batch_device", "cilqr_solve_batch_sampled", "cilqr_solve_batch_sampled_device",
-    "cilqr_argmin_device", "cilqr_wait", "cilqr_set_diag_buffer", "cilqr_set_pass_count_buffer", "cilqr_solve_family", "cilqr_solve_wavefronts", "cilqr_solve_sampled_wavefronts", "cilqr_debug_quu_inverse", "cilqr_debug_blur_ellipse", "cilqr_warp_costmap", "cilqr_warp_costmap_device", "cilqr_warp_costmap_batch_device", "cilqr_blur_costmap", "cilqr_blur_costmap_device", "cilqr_map_geom_set",
+    "cilqr_argmin_device", "cilqr_wait", "cilqr_set_diag_buffer", "cilqr_set_pass_count_buffer", "cilqr_solve_family", "cilqr_solve_wavefronts", "cilqr_solve_sampled_wavefronts", "cilqr_debug_quu_inverse", "cilqr_debug_closest_sample", "cilqr_debug_blur_ellipse", "cilqr_warp_costmap", "cilqr_warp_costmap_device", "cilqr_warp_costmap_batch_device", "cilqr_blur_costmap", "cilqr_blur_costmap_device", "cilqr_map_geom_set",
     "cilqr_occupancy_to_layer", "cilqr_occupancy_to_layer_device", "cilqr_layer_to_occupancy", "cilqr_layer_to_occupancy_device",
     "cilqr_costmap_frame_device",
     "cilqr_set_uncertainty_map", "cilqr_set_uncertainty_map_device", "cilqr_clear_uncertainty_map", "cilqr_debug_uncertainty_cost",
@@ -367,6 +367,13 @@ class Solver:
         lamb = _np64(lamb).reshape(-1)
         out = np.zeros_like(Quu)
         _check(lib().cilqr_debug_quu_inverse(self._h, int(Quu.shape[0]), _p(Quu), _p(lamb), _p(out), int(bool(general))))
+        return out
+
+    def debug_closest_sample(self, queries):
+        """`cilqr_debug_closest_sample`: rows {poly[6], x_first, x_last, px, py} → int32 rows {search, full scan, by Newton}."""
+        q = _np64(queries).reshape(-1, 10)
+        out = np.zeros((q.shape[0], 3), dtype=np.int32)
+        _check(lib().cilqr_debug_closest_sample(self._h, int(q.shape[0]), _p(q), out.ctypes.data_as(_ip)))
         return out
 
     def debug_blur_ellipse(self, abc):

@@ -410,6 +410,21 @@ int cilqr_debug_quu_inverse(cilqr_handle* h, int n, const double* Quu, const dou
   return CILQR_OK;
 }
 
+int cilqr_debug_closest_sample(cilqr_handle* h, int n, const double* queries, int32_t* out) {
+  if (!h || n < 1 || !queries || !out) return fail(CILQR_ERR_ARG, "cilqr_debug_closest_sample: bad argument");
+  HIP_TRY(hipSetDevice(h->device));
+  void* v = nullptr;
+  int rc = cilqr::scratch_bytes(h, cilqr::SCR_DEBUG, (sizeof(double) * 10 + sizeof(int32_t) * 4) * (size_t)n, &v);
+  if (rc) return rc;
+  double* din = (double*)v;
+  int32_t* dout = reinterpret_cast<int32_t*>(din + 10 * (size_t)n);
+  HIP_TRY(hipMemcpyAsync(din, queries, sizeof(double) * 10 * n, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(cilqr::launch_closest_sample(n, h->kp.n_samples, din, dout, h->stream));
+  HIP_TRY(hipMemcpyAsync(out, dout, sizeof(int32_t) * 3 * n, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CILQR_OK;
+}
+
 int cilqr_debug_blur_ellipse(cilqr_handle* h, int n, const double* abc, double* out) {
   if (!h || n < 1 || !abc || !out) return fail(CILQR_ERR_ARG, "cilqr_debug_blur_ellipse: bad argument");
   HIP_TRY(hipSetDevice(h->device));

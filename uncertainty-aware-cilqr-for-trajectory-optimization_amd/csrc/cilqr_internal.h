@@ -94,6 +94,7 @@ size_t solve_groups_ws_doubles(int B, int N);
 // Test hook: the map cost alone at n states [n][4] → cost[n], vx[n][2], mx[n][3] (solve 0's layer and pose).
 hipError_t launch_unc_cost(const UncArgs& u, int n, const double* states, double* cost, double* vx, double* mx, hipStream_t stream);
 hipError_t launch_quu_inverse(int n, const double* q, const double* lamb, double* out, int general, hipStream_t stream);
+hipError_t launch_closest_sample(int n, int S, const double* in, int32_t* out, hipStream_t stream);  // test hook (cilqr_debug_closest_sample)
 
 // Batched LocalPlanner (local_plan.hip): one lane per candidate.
 struct LocalPlanArgs {

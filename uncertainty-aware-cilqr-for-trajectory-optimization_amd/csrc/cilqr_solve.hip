@@ -1921,6 +1921,39 @@ __global__ void quu_inverse_kernel(int n, const double* q, const double* lamb, d
   out[4 * i] = ok ? i00 : nan; out[4 * i + 1] = ok ? i01 : nan; out[4 * i + 2] = ok ? i01 : nan; out[4 * i + 3] = ok ? i11 : nan;
 }
 
+// Test hook: the closest-sample search on n independent queries (one lane each), beside the plain scan over ALL samples.
+// in[i] = {poly[6], x_first, x_last, px, py}; out[i] = {index by closest_sample, index by the full scan, 1 if the Newton search decided}.
+__global__ void closest_sample_kernel(int n, int S, const double* in, int32_t* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* q = in + (size_t)i * 10;
+  double pc[CILQR_POLY_COEFFS];
+  for (int j = 0; j < CILQR_POLY_COEFFS; ++j) pc[j] = q[j];
+  SampleGrid g;
+  make_sample_grid(g, q[6], q[7], S);
+  auto at = [&](int s, double& x, double& y) { sample_xy(g, pc, s, x, y); };
+  double m = 0.0, A = 0.0, B = 0.0, yp = 0.0;
+  for (int s = 0; s < S; ++s) {  // what a solve kernel's prologue forms once per solve
+    double x, y, a2, a3;
+    at(s, x, y);
+    if (s > 0) { const double d = fabs(y - yp); m = fmax(m, d == d ? d : __builtin_huge_val()); }
+    yp = y;
+    path_curvature_terms(pc, x, a2, a3);
+    A = fmax(A, a2 == a2 ? a2 : __builtin_huge_val());
+    B = fmax(B, a3 == a3 ? a3 : __builtin_huge_val());
+  }
+  g.dmax = m;
+  g.p2 = path_curvature_bound(g, pc, S, A, B);
+  g.pc = pc;
+  const double px = q[8], py = q[9];
+  XWindow w = closest_window_x(S, g, px, py, at);
+  closest_window_y(S, g, px, py, w);
+  const int by_newton = w.hi - w.lo >= NEWTON_MIN_WINDOW ? closest_newton(S, g, px, py, at, w) : -1;
+  out[3 * (size_t)i] = closest_sample(S, g, px, py, at);
+  out[3 * (size_t)i + 1] = closest_scan(0, S - 1, px, py, at);
+  out[3 * (size_t)i + 2] = by_newton >= 0 ? 1 : 0;
+}
+
 __global__ void unc_cost_kernel(UncArgs u, int n, const double* states, double* cost, double* vx, double* mx) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -2030,6 +2063,12 @@ hipError_t launch_schedule_order(const int32_t* passes, int B, int32_t* order, h
 hipError_t launch_unc_cost(const UncArgs& u, int n, const double* states, double* cost, double* vx, double* mx, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(unc_cost_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, u, n, states, cost, vx, mx);
+  return hipGetLastError();
+}
+
+hipError_t launch_closest_sample(int n, int S, const double* in, int32_t* out, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(closest_sample_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, n, S, in, out);
   return hipGetLastError();
 }
 
