@@ -112,11 +112,14 @@ static int pick_split_wavefronts(const cilqr_handle* h, int B) {
 // Static obstacles on the one-wavefront family: a second wavefront per solve for phase L (cilqr_solve_share_kernel) up to TWO solves per
 // SIMD — tools/share_ab.py, profiles/r03_share_kernel.txt: config-2 scenes 0.372 against 0.404 ms at B = 256, 0.390 / 0.415 at 1024,
 // 0.406 / 0.433 at 2048, level at 3072, slower at 4096 (0.547 / 0.476: the second wavefronts cost residency there).
-// Up to ONE solve per SIMD three: the obstacle terms on two of them (even / odd entries: obstacle_loop's own two chains), Jacobians and
-// control barrier on the last — the solves that decide such a launch are the ones with every obstacle close.  0: one wavefront.
+// Up to THREE QUARTERS of a solve per SIMD three: the obstacle terms on two of them (even / odd entries: obstacle_loop's own two chains),
+// Jacobians and control barrier on the last — the solves that decide such a launch are the ones with every obstacle close (B = 256: 0.356
+// against 0.362 ms).  Not at one solve per SIMD: three wavefronts of 153 registers fill a SIMD, so a CU holds exactly its four workgroups
+// and every unevenness of the dispatch makes one wait for a whole solve (rocprofv3, 61 launches at B = 1024: 395 µs average, 538 µs
+// maximum with three; 391 / 418 with two).  0: one wavefront.
 static int pick_share(const cilqr_handle* h, int B, int M) {
   if (h->share_off || B > h->share_max) return 0;
-  const int w = h->share_w ? h->share_w : (B <= h->simds ? 3 : 2);
+  const int w = h->share_w ? h->share_w : (4 * B <= 3 * h->simds ? 3 : 2);
   return w == 3 && M < 2 ? 2 : w;
 }
 
