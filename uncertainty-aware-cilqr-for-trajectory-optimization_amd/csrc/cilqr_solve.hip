@@ -1770,6 +1770,10 @@ __global__ __launch_bounds__(W * WAVE, W) void cilqr_solve_share_kernel(SolveArg
       unsigned long long* o = a.diag + (size_t)b * DIAG_SLOTS;
       o[8] = busy; o[9] = calls;
     }
+    // where this wavefront ran: HW_ID (wave slot, SIMD, CU, shader array, shader engine) | XCC_ID << 32 (tools/wave_placement.py)
+    if (DIAG && lane == 0 && a.diag)
+      a.diag[(size_t)b * DIAG_SLOTS + 12 + wave] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
+                                                    ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) << 32);
     if (DIAG && lane == 0 && a.diag && wave == 2) a.diag[(size_t)b * DIAG_SLOTS + 11] = busy;
     return;
   }
@@ -1903,8 +1907,10 @@ __global__ __launch_bounds__(W * WAVE, W) void cilqr_solve_share_kernel(SolveArg
     unsigned long long* o = a.diag + (size_t)b * DIAG_SLOTS;
     o[0] = c_pro; o[1] = c_L; o[2] = c_R; o[3] = c_F; o[4] = now_ - tk; o[5] = n_L; o[6] = n_R; o[7] = now_ - tk0;
     o[10] = c_wait;
-    for (int q = 12; q < DIAG_SLOTS; ++q) o[q] = 0;
-    if (W == 2) o[11] = 0;
+    o[12] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
+            ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) << 32);
+    if (W == 2) { o[11] = 0; o[14] = 0; }
+    o[15] = 0;
   }
 #undef CILQR_STAMP
 }
