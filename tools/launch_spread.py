@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""How evenly a batch that fits the chip at once lies on it: the durations of K back-to-back launches of one config-2 batch (HIP
-events around every launch, no host synchronisation in between — as bench.py enqueues them), on a handle with the balanced LDS
-request (cilqr_api.cpp, balanced_lds_bytes) and on one created with CILQR_NO_LDS_BALANCE.
+"""The durations of K launches of one config-2 batch, HIP events around every launch: enqueued back to back (no host synchronisation
+in between — as bench.py enqueues its steps) and with a synchronisation after every launch.  Back to back, every other launch of a
+batch that fills the chip takes ≈ 25 µs longer (MI355X, round 3; the placement of the wavefronts is the same in both:
+tools/wave_placement.py); synchronised, all take the shorter time.
 
     python tools/launch_spread.py [B] [K]
 """
@@ -19,18 +20,16 @@ p = cilqr_amd.default_params(N)
 sc = scenes.make_static(B, N, M, p, scenes.SEED0 + 2)
 dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 x0, U0, poly, xpl, pose, dim = (dv(sc[k]) for k in ("x0", "U", "poly", "xplan_fl", "obs_pose", "obs_dim"))
-handles = {}
-handles["balanced"] = cilqr_amd.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M)
-os.environ["CILQR_NO_LDS_BALANCE"] = "1"
-handles["as placed"] = cilqr_amd.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M)
-del os.environ["CILQR_NO_LDS_BALANCE"]
+solver = cilqr_amd.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M)
+handles = {"back to back": False, "synchronised": True}
 X = torch.zeros(B, 4 * (N + 1), dtype=torch.float64, device="cuda"); J = torch.zeros(B, dtype=torch.float64, device="cuda")
 it = torch.zeros(B, dtype=torch.int32, device="cuda"); st = torch.zeros(B, dtype=torch.int32, device="cuda")
 U = U0.clone()
 stream = torch.cuda.current_stream().cuda_stream
-print("config-2 scenes, B = %d, %d wavefronts per solve; %d back-to-back launches per run, three runs per handle, in turns" % (B, handles["balanced"].solve_wavefronts(B, N, M), K))
+print("config-2 scenes, B = %d, %d wavefronts per solve; %d launches per run, three runs per mode, in turns" % (B, solver.solve_wavefronts(B, N, M), K))
 for rep in range(3):
-    for name, s in handles.items():
+    for name, sync in handles.items():
+        s = solver
         e0 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
         e1 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
         torch.cuda.synchronize()
@@ -40,9 +39,10 @@ for rep in range(3):
             s.solve_batch_device(stream, B, N, M, x0.data_ptr(), U.data_ptr(), poly.data_ptr(), xpl.data_ptr(), pose.data_ptr(), dim.data_ptr(), 0,
                                  X.data_ptr(), J.data_ptr(), it.data_ptr(), st.data_ptr())
             e1[k].record()
+            if sync:
+                torch.cuda.synchronize()
         torch.cuda.synchronize()
         d = np.array([a.elapsed_time(b) for a, b in zip(e0, e1)])[4:]
-        print("%-10s run %d: min %.4f  median %.4f  mean %.4f  max %.4f ms | launches above 1.05 x min: %d of %d | first 16: %s"
+        print("%-12s run %d: min %.4f  median %.4f  mean %.4f  max %.4f ms | launches above 1.05 x min: %d of %d | first 16: %s"
               % (name, rep, d.min(), np.median(d), d.mean(), d.max(), int((d > 1.05 * d.min()).sum()), len(d), " ".join("%.0f" % (1e3 * v) for v in d[:16])), flush=True)
-for s in handles.values():
-    s.close()
+solver.close()
