@@ -1,7 +1,8 @@
 """Randomised parity sweep (`-m gpu`): shapes, kernel families and lane groupings, parameter sets, weights and warm starts drawn
 from a seeded generator, every draw through the C-ABI against the oracle.  The fixed cases of test_gpu_parity.py pin named
 behaviours; this sweep looks for what nobody thought of naming — in particular in the paths added in round 3 (lane sharing in
-the grouped family, two and four wavefronts per sampled solve), whose lane ↔ step maps depend on the shape in many ways."""
+the grouped family, two and four wavefronts per sampled solve, two and three per static-obstacle solve), whose lane ↔ step maps
+depend on the shape in many ways."""
 import numpy as np
 import pytest
 
@@ -30,7 +31,7 @@ def _tweak(p, rng):
     return p
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(18))
 def test_random_static_scenes(cilqr, oracle, monkeypatch, seed):
     from cilqr_amd import scenes
     rng = np.random.default_rng(9100 + seed)
@@ -38,6 +39,13 @@ def test_random_static_scenes(cilqr, oracle, monkeypatch, seed):
     G = int(rng.choice([0, 1, 2, 4, 8, 16, 32, 64]))
     if G:
         monkeypatch.setenv("CILQR_FORCE_G", str(G))
+    # one wavefront per solve, or two / three sharing phase L where that kernel applies (a generator of its own: the draws above and
+    # below are those of the first version of this test)
+    share = str(np.random.default_rng(9500 + seed).choice(["rule", "2", "3", "off"]))
+    if share == "off":
+        monkeypatch.setenv("CILQR_NO_SHARE_KERNEL", "1")
+    elif share != "rule":
+        monkeypatch.setenv("CILQR_SHARE_W", share)
     p, po = cilqr.default_params(N), oracle.default_params(N)
     if seed % 2:
         state = rng.bit_generator.state
@@ -63,7 +71,50 @@ def test_random_static_scenes(cilqr, oracle, monkeypatch, seed):
         s.close()
     want = oracle.solve_batch(po, N, M, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"], sc["obs_weight"],
                               threads=min(16, oracle.max_threads()))
-    _compare(got, want, "seed %d: N=%d M=%d B=%d G=%d" % (seed, N, M, B, G))
+    _compare(got, want, "seed %d: N=%d M=%d B=%d G=%d share=%s" % (seed, N, M, B, G, share))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_static_scenes_wavefront_family(cilqr, oracle, monkeypatch, seed):
+    """The one-wavefront family on its own: one, two or three wavefronts per solve (cilqr_solve_share_kernel where the shape allows it,
+    cilqr_solve_kernel otherwise), horizons up to the 63 the shared kernel takes and a little beyond, tables that fit LDS and tables
+    that do not, weights, warm starts, moving obstacles, parameter sets off the defaults."""
+    from cilqr_amd import scenes
+    rng = np.random.default_rng(9600 + seed)
+    N, M, B = int(rng.integers(1, 70)), int(rng.integers(0, 11)), int(rng.integers(1, 700))
+    share = ["rule", "2", "3", "off"][seed % 4]
+    monkeypatch.setenv("CILQR_FORCE_G", "64")
+    if share == "off":
+        monkeypatch.setenv("CILQR_NO_SHARE_KERNEL", "1")
+    elif share != "rule":
+        monkeypatch.setenv("CILQR_SHARE_W", share)
+    p, po = cilqr.default_params(N), oracle.default_params(N)
+    if seed % 3 == 0:
+        state = rng.bit_generator.state
+        _tweak(p, rng)
+        rng.bit_generator.state = state
+        _tweak(po, rng)
+    sc = scenes.make_static(B, N, M, p, 9700 + seed)
+    if M and rng.random() < 0.5:
+        sc["obs_weight"] = rng.uniform(0.2, 2.0, (B, M))
+    if rng.random() < 0.5:
+        sc["U"] = sc["U"] + rng.normal(0.0, 0.25, sc["U"].shape)
+    if M and rng.random() < 0.5:
+        pose = sc["obs_pose"].reshape(B, M, N, 4).copy()
+        v = rng.uniform(0.0, 6.0, (B, M, 1))
+        pose[..., 2] = v
+        pose[..., 0] += v * np.cos(pose[..., 3]) * p.timestep * np.arange(N)
+        pose[..., 1] += v * np.sin(pose[..., 3]) * p.timestep * np.arange(N)
+        sc["obs_pose"] = pose.reshape(B, M, 4 * N)
+    s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=max(M, 1), device=0)
+    try:
+        w = s.solve_wavefronts(B, N, M)
+        got = s.solve_batch(N, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"], sc["obs_weight"])
+    finally:
+        s.close()
+    want = oracle.solve_batch(po, N, M, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"], sc["obs_weight"],
+                              threads=min(16, oracle.max_threads()))
+    _compare(got, want, "seed %d: N=%d M=%d B=%d share=%s -> %d wavefront(s) per solve" % (seed, N, M, B, share, w))
 
 
 @pytest.mark.parametrize("seed", range(8))

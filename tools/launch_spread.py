@@ -21,20 +21,24 @@ sc = scenes.make_static(B, N, M, p, scenes.SEED0 + 2)
 dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 x0, U0, poly, xpl, pose, dim = (dv(sc[k]) for k in ("x0", "U", "poly", "xplan_fl", "obs_pose", "obs_dim"))
 solver = cilqr_amd.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M)
-handles = {"back to back": False, "synchronised": True}
+# mode: (synchronise after every launch, extra trivial dispatches enqueued before every launch)
+handles = {"back to back": (False, 0), "synchronised": (True, 0), "one extra dispatch": (False, 1), "two extra dispatches": (False, 2)}
+dummy = torch.zeros(64, device="cuda")
 X = torch.zeros(B, 4 * (N + 1), dtype=torch.float64, device="cuda"); J = torch.zeros(B, dtype=torch.float64, device="cuda")
 it = torch.zeros(B, dtype=torch.int32, device="cuda"); st = torch.zeros(B, dtype=torch.int32, device="cuda")
 U = U0.clone()
 stream = torch.cuda.current_stream().cuda_stream
 print("config-2 scenes, B = %d, %d wavefronts per solve; %d launches per run, three runs per mode, in turns" % (B, solver.solve_wavefronts(B, N, M), K))
 for rep in range(3):
-    for name, sync in handles.items():
+    for name, (sync, extra) in handles.items():
         s = solver
         e0 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
         e1 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
         torch.cuda.synchronize()
         for k in range(K):
             U.copy_(U0)
+            for _ in range(extra):
+                dummy.add_(1.0)
             e0[k].record()
             s.solve_batch_device(stream, B, N, M, x0.data_ptr(), U.data_ptr(), poly.data_ptr(), xpl.data_ptr(), pose.data_ptr(), dim.data_ptr(), 0,
                                  X.data_ptr(), J.data_ptr(), it.data_ptr(), st.data_ptr())
@@ -43,6 +47,6 @@ for rep in range(3):
                 torch.cuda.synchronize()
         torch.cuda.synchronize()
         d = np.array([a.elapsed_time(b) for a, b in zip(e0, e1)])[4:]
-        print("%-12s run %d: min %.4f  median %.4f  mean %.4f  max %.4f ms | launches above 1.05 x min: %d of %d | first 16: %s"
+        print("%-20s run %d: min %.4f  median %.4f  mean %.4f  max %.4f ms | launches above 1.05 x min: %d of %d | first 16: %s"
               % (name, rep, d.min(), np.median(d), d.mean(), d.max(), int((d > 1.05 * d.min()).sum()), len(d), " ".join("%.0f" % (1e3 * v) for v in d[:16])), flush=True)
 solver.close()
