@@ -49,4 +49,22 @@ for rep in range(3):
         d = np.array([a.elapsed_time(b) for a, b in zip(e0, e1)])[4:]
         print("%-20s run %d: min %.4f  median %.4f  mean %.4f  max %.4f ms | launches above 1.05 x min: %d of %d | first 16: %s"
               % (name, rep, d.min(), np.median(d), d.mean(), d.max(), int((d > 1.05 * d.min()).sum()), len(d), " ".join("%.0f" % (1e3 * v) for v in d[:16])), flush=True)
+# The stamped instantiation in the same process: duration by events and the longest solve's length in shader clocks, launch by launch —
+# equal clocks with alternating durations mean the CLOCK alternates, not the work.
+diag = [torch.zeros(B, 16, dtype=torch.int64, device="cuda") for _ in range(16)]
+e0 = [torch.cuda.Event(enable_timing=True) for _ in range(16)]
+e1 = [torch.cuda.Event(enable_timing=True) for _ in range(16)]
+torch.cuda.synchronize()
+for k in range(16):
+    solver.set_diag_buffer(diag[k].data_ptr())
+    U.copy_(U0)
+    e0[k].record()
+    solver.solve_batch_device(stream, B, N, M, x0.data_ptr(), U.data_ptr(), poly.data_ptr(), xpl.data_ptr(), pose.data_ptr(), dim.data_ptr(), 0,
+                              X.data_ptr(), J.data_ptr(), it.data_ptr(), st.data_ptr())
+    e1[k].record()
+torch.cuda.synchronize()
+print("stamped instantiation, 16 launches: ms | longest solve in shader ticks | ticks per ns")
+for k in range(16):
+    ms, ticks = e0[k].elapsed_time(e1[k]), int(diag[k][:, 7].max().item())
+    print("   launch %2d: %.4f ms | %d | %.3f" % (k, ms, ticks, ticks / (ms * 1e6)))
 solver.close()
