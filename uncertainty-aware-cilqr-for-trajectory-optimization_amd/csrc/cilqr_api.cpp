@@ -138,7 +138,7 @@ static int launch_wave_scheduled(cilqr_handle* h, cilqr::SolveArgs& a, void* str
   // new trajectory behind the forward pass (cilqr_solve_pair_kernel).  Measured slower at every batch size (the
   // second wavefront's work is paid for by the main wavefronts that share its SIMD): an experiment, not the default.
   a.pair = h->pair_on && a.B <= h->simds ? 1 : 0;
-  // Default up to one solve per SIMD (share_max solves): a second wavefront per solve takes the obstacle, control-barrier and Jacobian
+  // Default up to two solves per SIMD (share_max solves): further wavefronts per solve take the obstacle, control-barrier and Jacobian
   // terms of phase L while the first searches the closest samples (cilqr_solve_share_kernel; bit-identical results; the launcher
   // falls back where it does not apply: table not in LDS, N > 63, a map set, the reference-loop mode).
   if (!a.pair) a.pair = pick_share(h, a.B, a.M);

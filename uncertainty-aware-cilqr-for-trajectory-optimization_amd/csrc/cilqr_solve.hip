@@ -1635,7 +1635,7 @@ __global__ __launch_bounds__(W * WAVE, 2) void cilqr_solve_split_kernel(SolveArg
 // two meet at two barriers per pass.  While every SIMD still holds a main wavefront the aux wavefronts take issue slots from the
 // main wavefronts of OTHER solves (work-conserving: no gain, no loss to speak of); once the short solves have ended — the larger
 // part of the launch — the long ones have their SIMDs' partners to themselves and a pass is ≈ 4.5 k ticks shorter.
-// W = 3 (up to one solve per SIMD): the obstacle terms are split once more — wavefront 1 sums the entries of EVEN index, wavefront 2
+// W = 3 (up to three quarters of a solve per SIMD: cilqr_api.cpp, pick_share): the obstacle terms are split once more — wavefront 1 sums the entries of EVEN index, wavefront 2
 // those of odd index, each in one chain, in order, which is obstacle_loop's own order of summation (cilqr_device.hpp, SPLIT); wavefront
 // 2 also takes the Jacobian slots and the control barrier, and main adds odd sums to even sums as obstacle_loop does.  The solves that
 // decide a launch are the ones with every obstacle close (their aux wavefront took 6.1 k ticks per call where the mean took 4.3 k).
