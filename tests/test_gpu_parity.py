@@ -494,7 +494,7 @@ def _same_bits(got, ref, what):
         assert np.array_equal(got[k], ref[k], equal_nan=(k in ("U", "X", "J"))), "%s: %s differs" % (what, k)
 
 
-@pytest.mark.parametrize("N,M,B", [(50, 4, 1024), (50, 4, 768), (50, 4, 2048), (30, 2, 200), (2, 1, 9), (1, 1, 3), (3, 0, 5), (17, 5, 64), (63, 4, 96), (33, 9, 70), (40, 3, 33)])
+@pytest.mark.parametrize("N,M,B", [(50, 4, 1024), (50, 4, 768), (50, 4, 2048), (50, 12, 300), (50, 8, 1024), (50, 30, 64), (50, 20, 400), (30, 2, 200), (2, 1, 9), (1, 1, 3), (3, 0, 5), (17, 5, 64), (63, 4, 96), (33, 9, 70), (40, 3, 33)])
 def test_share_kernel_changes_no_bit(cilqr, oracle, monkeypatch, N, M, B):
     """Up to two solves per SIMD a static-obstacle solve runs as a workgroup of two or three wavefronts that work on phase L at the same
     time (cilqr_solve_share_kernel: closest samples and tracking terms on one; cos / sin, obstacle sums — with three wavefronts the
@@ -552,7 +552,10 @@ def test_share_kernel_weights_warm_starts_and_hand_over(cilqr, oracle, monkeypat
         assert s.solve_wavefronts(64, 64, 4) == 1 and s.solve_wavefronts(64, 63, 4) == 3 and s.solve_wavefronts(64, 63, 1) == 2
         assert s.solve_wavefronts(3 * simds // 4, 50, 4) == 3 and s.solve_wavefronts(3 * simds // 4 + 1, 50, 4) == 2
         assert s.solve_wavefronts(2 * simds, 50, 4) == 2 and s.solve_wavefronts(2 * simds + 1, 50, 4) == 1
-        assert s.solve_wavefronts(64, 50, 40) == 1  # (the table of 40 obstacles × 50 steps does not fit the LDS share of a solve)
+        assert s.solve_wavefronts(64, 50, 80) == 1  # (the table of 80 obstacles × 50 steps does not fit a CU's LDS)
+        # a solve's LDS share grows where fewer solves share a CU: twelve obstacles fit up to two solves per CU, not at four; forty at one
+        assert s.solve_wavefronts(512, 50, 12) == 3 and s.solve_wavefronts(1024, 50, 12) == 1 and s.solve_wavefronts(1024, 50, 8) == 2
+        assert s.solve_wavefronts(64, 50, 40) == 3 and s.solve_wavefronts(300, 50, 40) == 1
     finally:
         s.close()
 

@@ -123,6 +123,19 @@ static int pick_share(const cilqr_handle* h, int B, int M) {
   return w == 3 && M < 2 ? 2 : w;
 }
 
+// LDS a solve of the one-wavefront family may take with its obstacle table inside.  32 KiB keeps five solves per CU resident — what a
+// batch beyond one solve per SIMD needs; a batch of at most k ≤ 4 solves per CU cannot use that residency, and each of its solves may
+// as well have 1/k of the CU's 160 KiB (beyond 64 KiB the launcher raises the kernels' limit): the table of up to ≈ 20 obstacles at two
+// solves per CU, ≈ 45 at one, then lies in LDS instead of being streamed from the workspace by every pass, and the shape can take the
+// shared-phase-L kernel (tools/share_ab.py, N = 50: M = 12 at B = 256 0.485 → 0.370 ms, M = 8 at B = 1024 0.503 → 0.435 ms).
+static int lds_table_budget(const cilqr_handle* h, int B) {
+  if (h->tab_budget_kb > 0) return h->tab_budget_kb * 1024;  // (environment CILQR_LDS_TABLE_KB at create: A/B hook)
+  const int cus = h->simds / 4, k = (B + cus - 1) / cus;
+  if (k < 1 || k > 4) return 32 * 1024;
+  const int share = (160 * 1024) / k - 2048;
+  return share < 32 * 1024 ? 32 * 1024 : share;
+}
+
 // The one-wavefront-per-solve family with a schedule hint.  A batch of more solves than SIMDs is dispatched in workgroup order,
 // and its launch ends when the last workgroup does: a 20-pass solve that starts among the last costs its full length on top of
 // everything else (config-2 scenes at B = 4096: 0.91 ms as given, 0.53 ms with the longest solves first; config 3: 3.8 → 2.4 ms,
@@ -142,6 +155,7 @@ static int launch_wave_scheduled(cilqr_handle* h, cilqr::SolveArgs& a, void* str
   // terms of phase L while the first searches the closest samples (cilqr_solve_share_kernel; bit-identical results; the launcher
   // falls back where it does not apply: table not in LDS, N > 63, a map set, the reference-loop mode).
   if (!a.pair) a.pair = pick_share(h, a.B, a.M);
+  a.tab_budget = lds_table_budget(h, a.B);
   HIP_TRY(cilqr::launch_solve_wave(a, (hipStream_t)stream));
   if (hinted) {
     HIP_TRY(cilqr::launch_schedule_order(h->d_hint_passes, a.B, h->d_order, (hipStream_t)stream));
@@ -255,6 +269,7 @@ int cilqr_create(const cilqr_params* p, int max_batch, int max_horizon, int max_
   h->steal_off = getenv("CILQR_NO_LANE_SHARING") != nullptr;
   h->split_off = getenv("CILQR_NO_SPLIT_KERNEL") != nullptr;
   h->share_off = getenv("CILQR_NO_SHARE_KERNEL") != nullptr;
+  if (const char* kb = getenv("CILQR_LDS_TABLE_KB")) h->tab_budget_kb = atoi(kb);
   h->share_max = 2 * h->simds;
   if (const char* sw = getenv("CILQR_SHARE_W")) h->share_w = atoi(sw) == 3 ? 3 : 2;  // (A/B hook: two or three wavefronts wherever the kernel applies)
   if (const char* sm = getenv("CILQR_SHARE_MAX_B")) h->share_max = atoi(sm);  // (A/B hook: largest batch on the shared-phase-L kernel)
@@ -457,7 +472,7 @@ int cilqr_solve_wavefronts(const cilqr_handle* h, int B, int N, int M) {
   if (!h || B < 0 || N < 1 || M < 0) return fail(CILQR_ERR_ARG, "cilqr_solve_wavefronts: bad argument");
   if (pick_group_lanes(h, B, N, M) != 64) return 1;
   const int w = pick_share(h, B, M);
-  return w && !h->pair_on && !h->unc.layer && cilqr::solve_share_applies(N, M, h->kp.n_samples) ? w : 1;
+  return w && !h->pair_on && !h->unc.layer && cilqr::solve_share_applies(N, M, h->kp.n_samples, lds_table_budget(h, B)) ? w : 1;
 }
 
 int cilqr_solve_sampled_wavefronts(const cilqr_handle* h, int B, int N, int n_obs) {
@@ -483,7 +498,7 @@ int cilqr_solve_batch_device(cilqr_handle* h, void* stream, int B, int N, int M,
   a.samp_off = nullptr; a.n_samples = 0; a.samp_w = 0.0;
   a.obs_tab = h->d_obs_tab;
   a.fwd = h->d_ws;  // (the grouped family's workspace: 42·N + 12 doubles per solve ≥ the 16·(N + 1) needed here; never both at once)
-  a.order = nullptr; a.hint_passes = nullptr; a.pair = 0; a.steal = h->steal_off ? 0 : 1; a.split = 0;
+  a.order = nullptr; a.hint_passes = nullptr; a.pair = 0; a.tab_budget = 0; a.steal = h->steal_off ? 0 : 1; a.split = 0;
   a.redo = h->d_redo;
   a.diag = h->diag;
   a.passes = h->passes;
@@ -540,7 +555,7 @@ int cilqr_solve_batch_sampled_device(cilqr_handle* h, void* stream, int B, int N
   a.samp_off = sample_offset; a.n_samples = n_samples; a.samp_w = sample_weight;
   a.obs_tab = h->d_obs_tab;  // n_obs·N·8 doubles per solve ≤ the n_obs·n_samples·N·6 reserved for the materialised form
   a.fwd = h->d_ws;
-  a.pair = 0; a.steal = 0;
+  a.pair = 0; a.tab_budget = 0; a.steal = 0;
   // wavefronts per solve sharing phase L (cilqr_solve_split_kernel): four up to one solve per SIMD, where a shorter pass is all that
   // counts, two beyond (tools/split_ab.py, profiles/r03_split_kernel.txt: B = 256 0.88 / 1.35 / 2.08 ms with 4 / 2 / 1 wavefronts,
   // B = 1024 1.47 / 1.55 / 2.11, B = 4096 3.86 / 3.27 / 3.97, B = 8192 6.81 / 5.48 / 5.68)

@@ -78,6 +78,7 @@ struct cilqr_handle {
   int split_w;         // 0 = automatic; else 2 or 4 (test hook: environment CILQR_SPLIT_W at create)
   int split_off;       // environment CILQR_NO_SPLIT_KERNEL at create: sampled obstacles on one wavefront per solve (A/B, tests)
   int share_off;       // environment CILQR_NO_SHARE_KERNEL at create: static obstacles on one wavefront per solve at every batch size (A/B, tests)
+  int tab_budget_kb;   // 0 = automatic (cilqr_api.cpp, lds_table_budget); else KiB (environment CILQR_LDS_TABLE_KB at create: A/B)
   int share_w;         // 0 = automatic (three wavefronts up to one solve per SIMD, two beyond); else 2 or 3 (environment CILQR_SHARE_W at create)
   int share_max;       // largest batch on the shared-phase-L kernel (cilqr_solve_share_kernel): the SIMD count; CILQR_SHARE_MAX_B overrides
   int pair_on;         // environment CILQR_PAIR_KERNEL at create: the two-wavefront kernel for batches up to one solve per SIMD

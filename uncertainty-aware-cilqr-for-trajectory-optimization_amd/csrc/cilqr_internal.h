@@ -70,6 +70,8 @@ struct SolveArgs {
   // 1: cilqr_solve_pair_kernel (the next linearisation runs behind the forward pass instead of after it; an experiment);
   // 2, 3: cilqr_solve_share_kernel with that many wavefronts (all of them work on phase L at the same time; the default)
   int32_t pair;
+  // one-wavefront family, static obstacles: LDS bytes a workgroup may take with its obstacle table inside (0: 32 KiB) — cilqr_api.cpp, lds_table_budget
+  int32_t tab_budget;
   // grouped family: 1 = in phase L the lanes of a wavefront's finished solves take steps of the unfinished ones (cilqr_solve_groups.hip)
   int32_t steal;
   // sampled obstacles: 1 = two wavefronts per solve share the obstacle entries of phase L (cilqr_solve.hip, cilqr_solve_split_kernel)
@@ -84,8 +86,8 @@ hipError_t launch_solve_wave(const SolveArgs& a, hipStream_t stream);
 hipError_t launch_schedule_order(const int32_t* passes, int B, int32_t* order, hipStream_t stream);  // passes descending
 size_t solve_lds_bytes(int N, int n_samples);
 constexpr size_t SOLVE_LDS_MAX = 160 * 1024;  // LDS of one CU: the horizon bound of the wavefront family
-bool solve_table_in_lds(int N, int M, int n_samples);   // static obstacles: the [M][N] entry table lies in LDS (else in the workspace)
-bool solve_share_applies(int N, int M, int n_samples);  // … and the shape can take cilqr_solve_share_kernel (two wavefronts share phase L)
+bool solve_table_in_lds(int N, int M, int n_samples, int budget);   // static obstacles: the [M][N] entry table lies in LDS (else in the workspace)
+bool solve_share_applies(int N, int M, int n_samples, int budget);  // … and the shape can take cilqr_solve_share_kernel (wavefronts share phase L)
 size_t solve_sampled_lds_bytes(int n_obs, int n_samples);   // additional LDS of the sampled-obstacle mode
 size_t solve_sampled_tab_doubles(int n_obs, int N);         // its workspace need per solve (in obs_tab)
 // G lanes per solve (G in {1,2,4,8,16,32}), workspace `ws` of solve_groups_ws_doubles(B, N) doubles (cilqr_solve_groups.hip).

@@ -2015,6 +2015,13 @@ template <int W, bool DIAG>
 hipError_t launch_shared_L(const SolveArgs& a, size_t tab_bytes, hipStream_t stream) {
   const size_t lds_fast = core_lds_bytes(a.N, a.kp.n_samples, true) + tab_bytes + ((((size_t)(W - 1) * 5 * a.N + 1) & ~(size_t)1) + 4) * sizeof(double);
   const size_t lds_general = core_lds_bytes(a.N, a.kp.n_samples, false) + tab_bytes;
+  if (lds_fast > 64 * 1024 || lds_general > 64 * 1024) {  // few solves per CU with large tables: more than the default 64 KiB of dynamic LDS
+    const int want = (int)(lds_fast > lds_general ? lds_fast : lds_general);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cilqr_solve_share_kernel<W, DIAG>), hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cilqr_solve_kernel<DIAG, 1, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    if (e != hipSuccess) return e;
+  }
   hipLaunchKernelGGL((cilqr_solve_share_kernel<W, DIAG>), dim3(a.B), dim3(W * WAVE), lds_fast, stream, a);
   hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, 1, true, false>), dim3(a.B), dim3(WAVE), lds_general, stream, a);
   return hipGetLastError();
@@ -2028,9 +2035,14 @@ hipError_t launch_pair(const SolveArgs& a, size_t extra, hipStream_t stream) {
 
 size_t solve_lds_bytes(int N, int n_samples) { return core_lds_bytes(N, n_samples, false); }  // the larger of the two layouts
 // Static obstacles: the table stays in LDS while a workgroup stays within 32 KiB (≥ 5 solves resident per CU of 160 KiB).  (M = 0: an empty table fits)
-bool solve_table_in_lds(int N, int M, int n_samples) { return solve_lds_bytes(N, n_samples) + (size_t)M * TABF * N * sizeof(double) <= 32 * 1024; }
+// `budget` (bytes; 0: those 32 KiB): what a workgroup may take where fewer solves than that share a CU — a batch of at most four solves
+// per CU leaves each of them a quarter of the CU's LDS, and the table in LDS is worth more than the residency nobody uses
+// (cilqr_api.cpp, lds_table_budget).
+bool solve_table_in_lds(int N, int M, int n_samples, int budget) {
+  return solve_lds_bytes(N, n_samples) + (size_t)M * TABF * N * sizeof(double) <= (size_t)(budget > 0 ? budget : 32 * 1024);
+}
 // … and whether a solve of this shape can take the shared-phase-L kernel (cilqr_solve_share_kernel): table in LDS, one state per lane
-bool solve_share_applies(int N, int M, int n_samples) { return N < WAVE && solve_table_in_lds(N, M, n_samples); }
+bool solve_share_applies(int N, int M, int n_samples, int budget) { return N < WAVE && solve_table_in_lds(N, M, n_samples, budget); }
 
 size_t solve_sampled_lds_bytes(int n_obs, int n_samples) {
   return ((size_t)n_obs * n_samples * OFFF + (size_t)2 * n_obs) * sizeof(double);  // offset records + rmax + constant-shape flags
@@ -2088,7 +2100,7 @@ hipError_t launch_solve_wave(const SolveArgs& a, hipStream_t stream) {
   if (a.B <= 0) return hipSuccess;
   const size_t lds = solve_lds_bytes(a.N, a.kp.n_samples);  // the larger layout: limits and the table decision hold for both kernels
   const size_t tab_bytes = (size_t)a.M * TABF * a.N * sizeof(double);
-  const bool tab_lds = a.n_samples == 0 && solve_table_in_lds(a.N, a.M, a.kp.n_samples);
+  const bool tab_lds = a.n_samples == 0 && solve_table_in_lds(a.N, a.M, a.kp.n_samples, a.tab_budget);
   if (a.n_samples > 0) {  // sampled obstacles: offset records in LDS, nominal records in the global workspace
     const size_t extra = solve_sampled_lds_bytes(a.M, a.n_samples);
     if (lds + extra > SOLVE_LDS_MAX) return hipErrorInvalidValue;  // checked by the caller
@@ -2116,7 +2128,7 @@ hipError_t launch_solve_wave(const SolveArgs& a, hipStream_t stream) {
   const size_t extra = tab_lds ? tab_bytes : 0;
   if (tab_lds && a.pair == 1 && !a.unc.layer && (a.flags & CILQR_FLAG_FAITHFUL_ITERS) == 0)
     return a.diag ? launch_two_wavefronts<true>(a, tab_bytes, stream) : launch_two_wavefronts<false>(a, tab_bytes, stream);
-  if (a.pair >= 2 && a.n_samples == 0 && solve_share_applies(a.N, a.M, a.kp.n_samples) && !a.unc.layer && (a.flags & CILQR_FLAG_FAITHFUL_ITERS) == 0) {
+  if (a.pair >= 2 && a.n_samples == 0 && solve_share_applies(a.N, a.M, a.kp.n_samples, a.tab_budget) && !a.unc.layer && (a.flags & CILQR_FLAG_FAITHFUL_ITERS) == 0) {
     if (a.pair == 3 && a.M >= 2) return a.diag ? launch_shared_L<3, true>(a, tab_bytes, stream) : launch_shared_L<3, false>(a, tab_bytes, stream);
     return a.diag ? launch_shared_L<2, true>(a, tab_bytes, stream) : launch_shared_L<2, false>(a, tab_bytes, stream);
   }
