@@ -82,6 +82,8 @@ def test_random_static_scenes_wavefront_family(cilqr, oracle, monkeypatch, seed)
     from cilqr_amd import scenes
     rng = np.random.default_rng(9600 + seed)
     N, M, B = int(rng.integers(1, 70)), int(rng.integers(0, 11)), int(rng.integers(1, 700))
+    if seed >= 8:  # (added with the long-horizon form of the shared kernel: horizons up to 130)
+        N += 62
     share = ["rule", "2", "3", "off"][seed % 4]
     monkeypatch.setenv("CILQR_FORCE_G", "64")
     if share == "off":

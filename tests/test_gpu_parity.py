@@ -494,19 +494,20 @@ def _same_bits(got, ref, what):
         assert np.array_equal(got[k], ref[k], equal_nan=(k in ("U", "X", "J"))), "%s: %s differs" % (what, k)
 
 
-@pytest.mark.parametrize("N,M,B", [(50, 4, 1024), (50, 4, 768), (50, 4, 2048), (50, 12, 300), (50, 8, 1024), (50, 30, 64), (50, 20, 400), (30, 2, 200), (2, 1, 9), (1, 1, 3), (3, 0, 5), (17, 5, 64), (63, 4, 96), (33, 9, 70), (40, 3, 33)])
+@pytest.mark.parametrize("N,M,B", [(50, 4, 1024), (50, 4, 768), (50, 4, 2048), (50, 12, 300), (50, 8, 1024), (50, 30, 64), (50, 20, 400), (80, 16, 64), (64, 3, 100), (127, 2, 30), (100, 6, 300), (30, 2, 200), (2, 1, 9), (1, 1, 3), (3, 0, 5), (17, 5, 64), (63, 4, 96), (33, 9, 70), (40, 3, 33)])
 def test_share_kernel_changes_no_bit(cilqr, oracle, monkeypatch, N, M, B):
     """Up to two solves per SIMD a static-obstacle solve runs as a workgroup of two or three wavefronts that work on phase L at the same
     time (cilqr_solve_share_kernel: closest samples and tracking terms on one; cos / sin, obstacle sums — with three wavefronts the
     entries of even index on one, of odd index on the other —, Jacobians and control barrier on the others).  The statements are
     lin_step's, whose obstacle terms are summed from zero in an even and an odd chain in every kernel: U, X, J, iterations and exit
-    reasons must be BIT-IDENTICAL to the one-wavefront kernel's — config 2 in full, two solves per SIMD, and ragged shapes
-    (N = 1, 2, 63; no obstacles, one, odd counts) — with three wavefronts and with two, and agree with the oracle."""
+    reasons must be BIT-IDENTICAL to the one-wavefront kernel's — config 2 in full, two solves per SIMD, ragged shapes (N = 1, 2, 63;
+    no obstacles, one, odd counts), crowded scenes whose table only fits LDS because few solves share a CU, horizons of 64 … 127 (two
+    steps per lane) — with three wavefronts and with two, and agree with the oracle."""
     from cilqr_amd import scenes
     p = cilqr.default_params(N)
     sc = scenes.make_static(B, N, M, p, 7300 + N)
     got, ref, w2, w1 = _share_vs_single(cilqr, monkeypatch, sc, N, M, B)
-    assert (w2, w1) == (3 if B <= 768 and M >= 2 else 2, 1)  # (MI355X: 1024 SIMDs; three wavefronts up to 3/4 solve per SIMD)
+    assert (w2, w1) == (3 if B <= 768 and M >= 2 and N < 64 else 2, 1)  # (MI355X: 1024 SIMDs; three wavefronts up to 3/4 solve per SIMD, N ≤ 63)
     _same_bits(got, ref, "%d wavefronts sharing phase L against one" % w2)
     if w2 == 3:  # the other wavefront count on the same shape
         monkeypatch.setenv("CILQR_SHARE_W", "2")
@@ -523,7 +524,7 @@ def test_share_kernel_weights_warm_starts_and_hand_over(cilqr, oracle, monkeypat
     """The shared-phase-L kernel with per-obstacle weights, warm-started (random) controls, a moving obstacle, and solves that it hands
     to the GENERAL kernel (a NaN start, a heading beyond the in-loop sincos range, a turn of more than 1/4 rad per step): the bits of
     the one-wavefront kernel, NaNs included, and the oracle's results where it has finite ones.  Where the kernel does not apply
-    (N = 64: one state per lane no longer fits; a batch beyond two solves per SIMD) the library says so and runs one wavefront."""
+    (N = 128: two steps per lane no longer cover the horizon; a batch beyond two solves per SIMD) the library says so and runs one wavefront."""
     from cilqr_amd import scenes
     N, M, B = 50, 6, 160
     p = cilqr.default_params(N)
@@ -549,7 +550,8 @@ def test_share_kernel_weights_warm_starts_and_hand_over(cilqr, oracle, monkeypat
     s = cilqr.Solver(cilqr.default_params(64), max_batch=8192, max_horizon=64, max_obstacles=4, device=0)
     try:
         simds = 1024  # MI355X: 256 CUs × 4
-        assert s.solve_wavefronts(64, 64, 4) == 1 and s.solve_wavefronts(64, 63, 4) == 3 and s.solve_wavefronts(64, 63, 1) == 2
+        assert s.solve_wavefronts(64, 128, 4) == 1 and s.solve_wavefronts(64, 127, 4) == 2 and s.solve_wavefronts(64, 64, 4) == 2
+        assert s.solve_wavefronts(64, 63, 4) == 3 and s.solve_wavefronts(64, 63, 1) == 2
         assert s.solve_wavefronts(3 * simds // 4, 50, 4) == 3 and s.solve_wavefronts(3 * simds // 4 + 1, 50, 4) == 2
         assert s.solve_wavefronts(2 * simds, 50, 4) == 2 and s.solve_wavefronts(2 * simds + 1, 50, 4) == 1
         assert s.solve_wavefronts(64, 50, 80) == 1  # (the table of 80 obstacles × 50 steps does not fit a CU's LDS)

@@ -117,10 +117,10 @@ static int pick_split_wavefronts(const cilqr_handle* h, int B) {
 // against 0.362 ms).  Not at one solve per SIMD: three wavefronts of 153 registers fill a SIMD, so a CU holds exactly its four workgroups
 // and every unevenness of the dispatch makes one wait for a whole solve (rocprofv3, 61 launches at B = 1024: 395 µs average, 538 µs
 // maximum with three; 391 / 418 with two).  0: one wavefront.
-static int pick_share(const cilqr_handle* h, int B, int M) {
+static int pick_share(const cilqr_handle* h, int B, int N, int M) {
   if (h->share_off || B > h->share_max) return 0;
   const int w = h->share_w ? h->share_w : (4 * B <= 3 * h->simds ? 3 : 2);
-  return w == 3 && M < 2 ? 2 : w;
+  return w == 3 && (M < 2 || N >= 64) ? 2 : w;  // (horizons 64 … 127: two steps per lane, built for two wavefronts)
 }
 
 // LDS a solve of the one-wavefront family may take with its obstacle table inside.  32 KiB keeps five solves per CU resident — what a
@@ -154,7 +154,7 @@ static int launch_wave_scheduled(cilqr_handle* h, cilqr::SolveArgs& a, void* str
   // Default up to two solves per SIMD (share_max solves): further wavefronts per solve take the obstacle, control-barrier and Jacobian
   // terms of phase L while the first searches the closest samples (cilqr_solve_share_kernel; bit-identical results; the launcher
   // falls back where it does not apply: table not in LDS, N > 63, a map set, the reference-loop mode).
-  if (!a.pair) a.pair = pick_share(h, a.B, a.M);
+  if (!a.pair) a.pair = pick_share(h, a.B, a.N, a.M);
   a.tab_budget = lds_table_budget(h, a.B);
   HIP_TRY(cilqr::launch_solve_wave(a, (hipStream_t)stream));
   if (hinted) {
@@ -471,7 +471,7 @@ int cilqr_solve_family(const cilqr_handle* h, int B, int N, int M) {
 int cilqr_solve_wavefronts(const cilqr_handle* h, int B, int N, int M) {
   if (!h || B < 0 || N < 1 || M < 0) return fail(CILQR_ERR_ARG, "cilqr_solve_wavefronts: bad argument");
   if (pick_group_lanes(h, B, N, M) != 64) return 1;
-  const int w = pick_share(h, B, M);
+  const int w = pick_share(h, B, N, M);
   return w && !h->pair_on && !h->unc.layer && cilqr::solve_share_applies(N, M, h->kp.n_samples, lds_table_budget(h, B)) ? w : 1;
 }
 

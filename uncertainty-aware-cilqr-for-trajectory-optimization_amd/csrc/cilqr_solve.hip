@@ -1644,8 +1644,11 @@ __global__ __launch_bounds__(W * WAVE, 2) void cilqr_solve_split_kernel(SolveArg
 // test_share_kernel_changes_no_bit).  Horizons up to 63 (one state per lane), obstacle table in LDS, no map, early-exit mode.
 // DIAG: a.diag[b] = {prologue, L (main's share + the wait at barrier A + the combine), R, F, epilogue, #L, #R, total, aux: busy
 // ticks, aux: calls, main: ticks waiting at barrier A, 0…}.
-template <int W, bool DIAG>
+// LONG: horizons 64 … 127, two steps per lane (two wavefronts only: the registers of a second step do not fit three wavefronts per SIMD).
+template <int W, bool LONG, bool DIAG>
 __global__ __launch_bounds__(W * WAVE, W) void cilqr_solve_share_kernel(SolveArgs a) {  // (W wavefronts per SIMD: ≤ 256 / 168 vector registers)
+  static_assert(!(LONG && W != 2), "the long-horizon form is built for two wavefronts");
+  constexpr int STEPS = LONG ? 2 : 1;  // steps per lane
   unsigned long long tk0 = 0, tk = 0, c_pro = 0, c_L = 0, c_R = 0, c_F = 0, n_L = 0, n_R = 0, c_wait = 0;
   if (DIAG) tk0 = tk = __builtin_readcyclecounter();
 #define CILQR_STAMP(acc)                                 \
@@ -1718,8 +1721,6 @@ __global__ __launch_bounds__(W * WAVE, W) void cilqr_solve_share_kernel(SolveArg
   grid.p2 = ctl[2];
   grid.pc = cst + CST_PC;
 
-  const int t = lane;
-  const bool act = t < N;
   if (wave != 0) {
     // ---- the aux wavefront: cos / sin, obstacle sums, control barrier, Jacobians — pass after pass -------------------------------------
     unsigned long long busy = 0, calls = 0;
@@ -1728,10 +1729,8 @@ __global__ __launch_bounds__(W * WAVE, W) void cilqr_solve_share_kernel(SolveArg
       unsigned long long t0 = 0;
       if (DIAG) t0 = __builtin_readcyclecounter();
       const KParams kpl = phase_params();
-      double sA = 0.0, cA = 1.0;
-      if (lane <= N) sincos_loop(Xa[lane * XR + 3], sA, cA);  // (headings within sincos_loop's range: rollout_fast, MAX_TURN)
-      const double cn = __shfl_down(cA, 1, WAVE), sn = __shfl_down(sA, 1, WAVE);
-      if (act) {
+      // one step of this wavefront's share: (cA, sA) = cos / sin of the step's heading, (cn, sn) of the next one
+      auto aux_step = [&](int t, double cA, double sA, double cn, double sn) {
         const double* xr = Xa + t * XR;
         const double u0 = Ua[2 * t], u1 = Ua[2 * t + 1];
         StepSums s5{0.0, 0.0, 0.0, 0.0, 0.0};
@@ -1761,6 +1760,22 @@ __global__ __launch_bounds__(W * WAVE, W) void cilqr_solve_share_kernel(SolveArg
             r[6] = c.lu0 * ih; r[7] = c.lu1; r[8] = c.luu0 * (ih * ih); r[9] = c.luu1;
           }
         }
+      };
+      double cn = 0.0;
+      if (!LONG) {  // one state per lane: a step's next heading comes from the lane above
+        double sA = 0.0, cA = 1.0;
+        if (lane <= N) sincos_loop(Xa[lane * XR + 3], sA, cA);  // (headings within sincos_loop's range: rollout_fast, MAX_TURN)
+        cn = __shfl_down(cA, 1, WAVE);
+        const double sn = __shfl_down(sA, 1, WAVE);
+        if (lane < N) aux_step(lane, cA, sA, cn, sn);
+      } else {         // horizons up to 127, two steps per lane: the last aux wavefront evaluates the next heading itself
+        for (int t = lane; t < N; t += WAVE) {
+          double sA, cA, sn = 0.0;
+          sincos_loop(Xa[t * XR + 3], sA, cA);
+          cn = 1.0;
+          if (wave == W - 1) sincos_loop(Xa[(t + 1) * XR + 3], sn, cn);
+          aux_step(t, cA, sA, cn, sn);
+        }
       }
       if (DIAG) { busy += stamp_after(cn) - t0; ++calls; }
       __syncthreads();  // A: sums and record slots are in LDS
@@ -1788,33 +1803,38 @@ __global__ __launch_bounds__(W * WAVE, W) void cilqr_solve_share_kernel(SolveArg
     ++iters;
     {  // phase L: forward-pass rows, closest sample, tracking terms, J; then the aux wavefront's sums on top
       const KParams kpl = phase_params();
-      double dx = 0.0, dy = 0.0, lx2 = 0.0, Jt = 0.0;
-      if (act) {
-        const double* xr = Xa + t * XR;
-        const double px = xr[0], py = xr[1], v = xr[2];
-        const double u0 = Ua[2 * t], u1 = Ua[2 * t + 1];
-        double2* q = reinterpret_cast<double2*>(fwd + t * FREC + 10);  // the forward pass reads the old state and control through the scalar path
-        q[0] = make_double2(px, py);
-        q[1] = make_double2(v, xr[3]);
-        q[2] = make_double2(u0, u1);
-        const int cs = closest_sample(S, grid, px, py, LdsSamples{samp, grid.xf, grid.dxs});
-        dx = px - fma(grid.dxs, (double)cs, grid.xf);
-        dy = py - samp[cs];
-        const double dv = v - kpl.desired_speed;
-        lx2 = (2 * kpl.w_vel) * dv;
-        Jt = stage_cost(kpl, dx, dy, dv, u0, u1);
-        if (W == 2) {  // control barrier (I/Constraints.cpp:110-131); with three wavefronts: on the last one
-          Rec c;
-          double a1, a2, a3, a4;
-          ctrl_args(kpl, u0, u1, v, a1, a2, a3, a4);
-          const double e1 = exp_fast(a1);
-          const double e2 = exp_fast(a2);
-          const double e3 = exp_fast(a3);
-          const double e4 = exp_fast(a4);
-          ctrl_terms(kpl, u0, u1, e1, e2, e3, e4, c);
-          double* r = rec + t * RECF;
-          const double ih = 2.0 / kpl.dt;  // production records: acceleration in units of (dt/2)·u0 (riccati_mfma)
-          r[6] = c.lu0 * ih; r[7] = c.lu1; r[8] = c.luu0 * (ih * ih); r[9] = c.luu1;
+      double dx[STEPS], dy[STEPS], lx2[STEPS], Jt = 0.0;  // (LONG: steps lane and lane + 64)
+#pragma unroll
+      for (int c2 = 0; c2 < STEPS; ++c2) {
+        dx[c2] = 0.0; dy[c2] = 0.0; lx2[c2] = 0.0;
+        const int t = lane + c2 * WAVE;
+        if (t < N) {
+          const double* xr = Xa + t * XR;
+          const double px = xr[0], py = xr[1], v = xr[2];
+          const double u0 = Ua[2 * t], u1 = Ua[2 * t + 1];
+          double2* q = reinterpret_cast<double2*>(fwd + t * FREC + 10);  // the forward pass reads the old state and control through the scalar path
+          q[0] = make_double2(px, py);
+          q[1] = make_double2(v, xr[3]);
+          q[2] = make_double2(u0, u1);
+          const int cs = closest_sample(S, grid, px, py, LdsSamples{samp, grid.xf, grid.dxs});
+          dx[c2] = px - fma(grid.dxs, (double)cs, grid.xf);
+          dy[c2] = py - samp[cs];
+          const double dv = v - kpl.desired_speed;
+          lx2[c2] = (2 * kpl.w_vel) * dv;
+          Jt += stage_cost(kpl, dx[c2], dy[c2], dv, u0, u1);
+          if (W == 2) {  // control barrier (I/Constraints.cpp:110-131); with three wavefronts: on the last one
+            Rec c;
+            double a1, a2, a3, a4;
+            ctrl_args(kpl, u0, u1, v, a1, a2, a3, a4);
+            const double e1 = exp_fast(a1);
+            const double e2 = exp_fast(a2);
+            const double e3 = exp_fast(a3);
+            const double e4 = exp_fast(a4);
+            ctrl_terms(kpl, u0, u1, e1, e2, e3, e4, c);
+            double* r = rec + t * RECF;
+            const double ih = 2.0 / kpl.dt;  // production records: acceleration in units of (dt/2)·u0 (riccati_mfma)
+            r[6] = c.lu0 * ih; r[7] = c.lu1; r[8] = c.luu0 * (ih * ih); r[9] = c.luu1;
+          }
         }
       }
       J_new = wave_sum_uniform(Jt);
@@ -1822,17 +1842,21 @@ __global__ __launch_bounds__(W * WAVE, W) void cilqr_solve_share_kernel(SolveArg
       if (DIAG) w0 = stamp_after(J_new);
       __syncthreads();  // A
       if (DIAG) c_wait += __builtin_readcyclecounter() - w0;
-      if (act) {
-        const double* q = part + (size_t)t * 5;
-        StepSums s5{q[0], q[1], q[2], q[3], q[4]};
-        if (W == 3) {  // odd sums onto even sums: obstacle_loop's last statement
-          const double* qo = q + (size_t)N * 5;
-          s5.lx0 += qo[0]; s5.lx1 += qo[1]; s5.h00 += qo[2]; s5.h01 += qo[3]; s5.h11 += qo[4];
+#pragma unroll
+      for (int c2 = 0; c2 < STEPS; ++c2) {
+        const int t = lane + c2 * WAVE;
+        if (t < N) {
+          const double* q = part + (size_t)t * 5;
+          StepSums s5{q[0], q[1], q[2], q[3], q[4]};
+          if (W == 3) {  // odd sums onto even sums: obstacle_loop's last statement
+            const double* qo = q + (size_t)N * 5;
+            s5.lx0 += qo[0]; s5.lx1 += qo[1]; s5.h00 += qo[2]; s5.h01 += qo[3]; s5.h11 += qo[4];
+          }
+          double* r = rec + t * RECF;
+          double lx0, lx1, l00, l01, l11;
+          state_terms(kpl, dx[c2], dy[c2], s5, lx0, lx1, l00, l01, l11);
+          r[0] = lx0; r[1] = lx1; r[2] = lx2[c2]; r[3] = l00; r[4] = l01; r[5] = l11;
         }
-        double* r = rec + t * RECF;
-        double lx0, lx1, l00, l01, l11;
-        state_terms(kpl, dx, dy, s5, lx0, lx1, l00, l01, l11);
-        r[0] = lx0; r[1] = lx1; r[2] = lx2; r[3] = l00; r[4] = l01; r[5] = l11;
       }
       j_valid = true;
     }
@@ -2010,19 +2034,19 @@ hipError_t launch_two_wavefronts(const SolveArgs& a, size_t tab_bytes, hipStream
   hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, 1, true, false>), dim3(a.B), dim3(WAVE), lds_general, stream, a);
   return hipGetLastError();
 }
-// The shared-phase-L kernel (table in LDS, no map, early exit, N ≤ 63) with the GENERAL kernel of the one-wavefront family behind it.
-template <int W, bool DIAG>
+// The shared-phase-L kernel (table in LDS, no map, early exit, N ≤ 127) with the GENERAL kernel of the one-wavefront family behind it.
+template <int W, bool LONG, bool DIAG>
 hipError_t launch_shared_L(const SolveArgs& a, size_t tab_bytes, hipStream_t stream) {
   const size_t lds_fast = core_lds_bytes(a.N, a.kp.n_samples, true) + tab_bytes + ((((size_t)(W - 1) * 5 * a.N + 1) & ~(size_t)1) + 4) * sizeof(double);
   const size_t lds_general = core_lds_bytes(a.N, a.kp.n_samples, false) + tab_bytes;
   if (lds_fast > 64 * 1024 || lds_general > 64 * 1024) {  // few solves per CU with large tables: more than the default 64 KiB of dynamic LDS
     const int want = (int)(lds_fast > lds_general ? lds_fast : lds_general);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cilqr_solve_share_kernel<W, DIAG>), hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cilqr_solve_share_kernel<W, LONG, DIAG>), hipFuncAttributeMaxDynamicSharedMemorySize, want);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cilqr_solve_kernel<DIAG, 1, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, want);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((cilqr_solve_share_kernel<W, DIAG>), dim3(a.B), dim3(W * WAVE), lds_fast, stream, a);
+  hipLaunchKernelGGL((cilqr_solve_share_kernel<W, LONG, DIAG>), dim3(a.B), dim3(W * WAVE), lds_fast, stream, a);
   hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, 1, true, false>), dim3(a.B), dim3(WAVE), lds_general, stream, a);
   return hipGetLastError();
 }
@@ -2041,8 +2065,8 @@ size_t solve_lds_bytes(int N, int n_samples) { return core_lds_bytes(N, n_sample
 bool solve_table_in_lds(int N, int M, int n_samples, int budget) {
   return solve_lds_bytes(N, n_samples) + (size_t)M * TABF * N * sizeof(double) <= (size_t)(budget > 0 ? budget : 32 * 1024);
 }
-// … and whether a solve of this shape can take the shared-phase-L kernel (cilqr_solve_share_kernel): table in LDS, one state per lane
-bool solve_share_applies(int N, int M, int n_samples, int budget) { return N < WAVE && solve_table_in_lds(N, M, n_samples, budget); }
+// … and whether a solve of this shape can take the shared-phase-L kernel (cilqr_solve_share_kernel): table in LDS, at most two steps per lane
+bool solve_share_applies(int N, int M, int n_samples, int budget) { return N < 2 * WAVE && solve_table_in_lds(N, M, n_samples, budget); }
 
 size_t solve_sampled_lds_bytes(int n_obs, int n_samples) {
   return ((size_t)n_obs * n_samples * OFFF + (size_t)2 * n_obs) * sizeof(double);  // offset records + rmax + constant-shape flags
@@ -2129,8 +2153,9 @@ hipError_t launch_solve_wave(const SolveArgs& a, hipStream_t stream) {
   if (tab_lds && a.pair == 1 && !a.unc.layer && (a.flags & CILQR_FLAG_FAITHFUL_ITERS) == 0)
     return a.diag ? launch_two_wavefronts<true>(a, tab_bytes, stream) : launch_two_wavefronts<false>(a, tab_bytes, stream);
   if (a.pair >= 2 && a.n_samples == 0 && solve_share_applies(a.N, a.M, a.kp.n_samples, a.tab_budget) && !a.unc.layer && (a.flags & CILQR_FLAG_FAITHFUL_ITERS) == 0) {
-    if (a.pair == 3 && a.M >= 2) return a.diag ? launch_shared_L<3, true>(a, tab_bytes, stream) : launch_shared_L<3, false>(a, tab_bytes, stream);
-    return a.diag ? launch_shared_L<2, true>(a, tab_bytes, stream) : launch_shared_L<2, false>(a, tab_bytes, stream);
+    if (a.N >= WAVE) return a.diag ? launch_shared_L<2, true, true>(a, tab_bytes, stream) : launch_shared_L<2, true, false>(a, tab_bytes, stream);
+    if (a.pair == 3 && a.M >= 2) return a.diag ? launch_shared_L<3, false, true>(a, tab_bytes, stream) : launch_shared_L<3, false, false>(a, tab_bytes, stream);
+    return a.diag ? launch_shared_L<2, false, true>(a, tab_bytes, stream) : launch_shared_L<2, false, false>(a, tab_bytes, stream);
   }
   if (a.diag) return tab_lds ? launch_pair<true, 1>(a, extra, stream) : launch_pair<true, 0>(a, extra, stream);
   return tab_lds ? launch_pair<false, 1>(a, extra, stream) : launch_pair<false, 0>(a, extra, stream);
