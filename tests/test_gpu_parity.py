@@ -607,9 +607,9 @@ def test_family_rule_on_measured_shapes(cilqr, oracle):
     s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=16, device=0)
     try:
         fam = s.solve_family
-        assert fam(1024, 50, 4) == 64 and fam(4096, 50, 4) == 64 and fam(8192, 50, 4) == 8 and fam(4096, 50, 8) == 16
+        assert fam(1024, 50, 4) == 64 and fam(4096, 50, 4) == 64 and fam(8192, 50, 4) == 8 and fam(4096, 50, 8) == 64 and fam(8192, 50, 8) == 8
         assert fam(8192, 30, 2) == 64 and fam(16384, 30, 2) == 4 and fam(2048, 64, 4) == 64 and fam(4096, 64, 4) == 16
-        assert fam(2048, 80, 16) == 32 and fam(8192, 80, 16) == 8 and fam(65536, 80, 16) == 4 and fam(65536, 50, 4) == 2
+        assert fam(2048, 80, 16) == 64 and fam(4096, 80, 16) == 16 and fam(8192, 80, 16) == 8 and fam(65536, 80, 16) == 4 and fam(65536, 50, 4) == 2
         assert fam(4096, 120, 4) == 64 and fam(16384, 160, 16) == 64 and fam(4096, 50, 256) == 64
         sc = scenes.make_static(B, N, M, p, 7400)
         got = _gpu_batch(s, sc)

@@ -84,10 +84,11 @@ static int pick_group_lanes(const cilqr_handle* h, int B, int N, int M) {
   if (M > 32 || N > 110) return 64;
   // largest batch that stays on the wavefront family, in half solves per SIMD
   int cap2;
+  // (redrawn at the end of round 3, when the family had got its shared-phase-L kernel up to two solves per SIMD and N = 127:
+  // profiles/r03_family_shapes.txt)
   if (N <= 32) cap2 = 16;
-  else if (N <= 56) cap2 = M <= 6 ? 8 : 4;
-  else if (N <= 64) cap2 = M <= 6 ? 4 : 3;
-  else if (N <= 92) cap2 = 3;
+  else if (N <= 56) cap2 = 8;
+  else if (N <= 92) cap2 = 4;
   else cap2 = 8;
   if (2L * B <= (long)cap2 * h->simds) return 64;
   int G = 32;
