@@ -494,7 +494,7 @@ def _same_bits(got, ref, what):
         assert np.array_equal(got[k], ref[k], equal_nan=(k in ("U", "X", "J"))), "%s: %s differs" % (what, k)
 
 
-@pytest.mark.parametrize("N,M,B", [(50, 4, 1024), (50, 4, 768), (50, 4, 2048), (50, 12, 300), (50, 8, 1024), (50, 30, 64), (50, 20, 400), (80, 16, 64), (64, 3, 100), (127, 2, 30), (100, 6, 300), (30, 2, 200), (2, 1, 9), (1, 1, 3), (3, 0, 5), (17, 5, 64), (63, 4, 96), (33, 9, 70), (40, 3, 33)])
+@pytest.mark.parametrize("N,M,B", [(50, 4, 1024), (50, 4, 768), (50, 4, 2048), (50, 12, 300), (50, 8, 1024), (50, 30, 64), (50, 20, 400), (80, 16, 64), (64, 3, 100), (64, 1, 40), (65, 2, 50), (127, 2, 30), (100, 6, 300), (30, 2, 200), (2, 1, 9), (1, 1, 3), (3, 0, 5), (17, 5, 64), (63, 4, 96), (33, 9, 70), (40, 3, 33)])
 def test_share_kernel_changes_no_bit(cilqr, oracle, monkeypatch, N, M, B):
     """Up to two solves per SIMD a static-obstacle solve runs as a workgroup of two or three wavefronts that work on phase L at the same
     time (cilqr_solve_share_kernel: closest samples and tracking terms on one; cos / sin, obstacle sums — with three wavefronts the
@@ -507,7 +507,7 @@ def test_share_kernel_changes_no_bit(cilqr, oracle, monkeypatch, N, M, B):
     p = cilqr.default_params(N)
     sc = scenes.make_static(B, N, M, p, 7300 + N)
     got, ref, w2, w1 = _share_vs_single(cilqr, monkeypatch, sc, N, M, B)
-    assert (w2, w1) == (3 if B <= 768 and M >= 2 and N < 64 else 2, 1)  # (MI355X: 1024 SIMDs; three wavefronts up to 3/4 solve per SIMD, N ≤ 63)
+    assert (w2, w1) == (3 if B <= 768 and M >= 2 and N <= 64 else 2, 1)  # (MI355X: 1024 SIMDs; three wavefronts up to 3/4 solve per SIMD, N ≤ 64)
     _same_bits(got, ref, "%d wavefronts sharing phase L against one" % w2)
     if w2 == 3:  # the other wavefront count on the same shape
         monkeypatch.setenv("CILQR_SHARE_W", "2")
@@ -550,7 +550,7 @@ def test_share_kernel_weights_warm_starts_and_hand_over(cilqr, oracle, monkeypat
     s = cilqr.Solver(cilqr.default_params(64), max_batch=8192, max_horizon=64, max_obstacles=4, device=0)
     try:
         simds = 1024  # MI355X: 256 CUs × 4
-        assert s.solve_wavefronts(64, 128, 4) == 1 and s.solve_wavefronts(64, 127, 4) == 2 and s.solve_wavefronts(64, 64, 4) == 2
+        assert s.solve_wavefronts(64, 128, 4) == 1 and s.solve_wavefronts(64, 127, 4) == 2 and s.solve_wavefronts(64, 65, 4) == 2 and s.solve_wavefronts(64, 64, 4) == 3
         assert s.solve_wavefronts(64, 63, 4) == 3 and s.solve_wavefronts(64, 63, 1) == 2
         assert s.solve_wavefronts(3 * simds // 4, 50, 4) == 3 and s.solve_wavefronts(3 * simds // 4 + 1, 50, 4) == 2
         assert s.solve_wavefronts(2 * simds, 50, 4) == 2 and s.solve_wavefronts(2 * simds + 1, 50, 4) == 1

@@ -110,8 +110,8 @@ static int pick_split_wavefronts(const cilqr_handle* h, int B) {
   return B <= h->simds ? 4 : 2;
 }
 
-// Static obstacles on the one-wavefront family: a second wavefront per solve for phase L (cilqr_solve_share_kernel) up to TWO solves per
-// SIMD — tools/share_ab.py, profiles/r03_share_kernel.txt: config-2 scenes 0.372 against 0.404 ms at B = 256, 0.390 / 0.415 at 1024,
+// Static obstacles on the one-wavefront family: further wavefronts per solve for phase L (cilqr_solve_share_kernel) up to about two solves
+// per SIMD — tools/share_ab.py, profiles/r03_share_kernel.txt: config-2 scenes 0.372 against 0.404 ms at B = 256, 0.390 / 0.415 at 1024,
 // 0.406 / 0.433 at 2048, level at 3072, slower at 4096 (0.547 / 0.476: the second wavefronts cost residency there).
 // Up to THREE QUARTERS of a solve per SIMD three: the obstacle terms on two of them (even / odd entries: obstacle_loop's own two chains),
 // Jacobians and control barrier on the last — the solves that decide such a launch are the ones with every obstacle close (B = 256: 0.356
@@ -119,9 +119,15 @@ static int pick_split_wavefronts(const cilqr_handle* h, int B) {
 // and every unevenness of the dispatch makes one wait for a whole solve (rocprofv3, 61 launches at B = 1024: 395 µs average, 538 µs
 // maximum with three; 391 / 418 with two).  0: one wavefront.
 static int pick_share(const cilqr_handle* h, int B, int N, int M) {
-  if (h->share_off || B > h->share_max) return 0;
+  // how far beyond one solve per SIMD the further wavefronts pay depends on how many workgroups a CU still holds, i.e. on the horizon
+  // (tools/share_ab.py with CILQR_SHARE_MAX_B open, profiles/r03_share_kernel.txt, last section: N = 30 still 6 % ahead at four solves
+  // per SIMD, N = 40 8 % at three, N = 50 8 % at two and level at three, N = 56 / 60 5 / 3 % at 1.5 and behind at two, N = 64 ahead at
+  // 1.25 and behind at 1.5, N = 80 2 % at one) — in quarters of a solve per SIMD:
+  const int q = N <= 32 ? 16 : N <= 44 ? 12 : N <= 52 ? 8 : N <= 60 ? 6 : N <= 64 ? 5 : 4;
+  const long cap = h->share_max >= 0 ? (long)h->share_max : (long)q * h->simds / 4;
+  if (h->share_off || B > cap) return 0;
   const int w = h->share_w ? h->share_w : (4 * B <= 3 * h->simds ? 3 : 2);
-  return w == 3 && (M < 2 || N >= 64) ? 2 : w;  // (horizons 64 … 127: two steps per lane, built for two wavefronts)
+  return w == 3 && (M < 2 || N > 64) ? 2 : w;  // (horizons 65 … 127: two steps per lane, built for two wavefronts)
 }
 
 // LDS a solve of the one-wavefront family may take with its obstacle table inside.  32 KiB keeps five solves per CU resident — what a
@@ -154,7 +160,7 @@ static int launch_wave_scheduled(cilqr_handle* h, cilqr::SolveArgs& a, void* str
   a.pair = h->pair_on && a.B <= h->simds ? 1 : 0;
   // Default up to two solves per SIMD (share_max solves): further wavefronts per solve take the obstacle, control-barrier and Jacobian
   // terms of phase L while the first searches the closest samples (cilqr_solve_share_kernel; bit-identical results; the launcher
-  // falls back where it does not apply: table not in LDS, N > 63, a map set, the reference-loop mode).
+  // falls back where it does not apply: table not in LDS, N > 127, a map set, the reference-loop mode).
   if (!a.pair) a.pair = pick_share(h, a.B, a.N, a.M);
   a.tab_budget = lds_table_budget(h, a.B);
   HIP_TRY(cilqr::launch_solve_wave(a, (hipStream_t)stream));
@@ -271,7 +277,7 @@ int cilqr_create(const cilqr_params* p, int max_batch, int max_horizon, int max_
   h->split_off = getenv("CILQR_NO_SPLIT_KERNEL") != nullptr;
   h->share_off = getenv("CILQR_NO_SHARE_KERNEL") != nullptr;
   if (const char* kb = getenv("CILQR_LDS_TABLE_KB")) h->tab_budget_kb = atoi(kb);
-  h->share_max = 2 * h->simds;
+  h->share_max = -1;  // by horizon (pick_share)
   if (const char* sw = getenv("CILQR_SHARE_W")) h->share_w = atoi(sw) == 3 ? 3 : 2;  // (A/B hook: two or three wavefronts wherever the kernel applies)
   if (const char* sm = getenv("CILQR_SHARE_MAX_B")) h->share_max = atoi(sm);  // (A/B hook: largest batch on the shared-phase-L kernel)
   if (const char* sw = getenv("CILQR_SPLIT_W")) h->split_w = atoi(sw);  // (test hook: 2 or 4 wavefronts per solve)

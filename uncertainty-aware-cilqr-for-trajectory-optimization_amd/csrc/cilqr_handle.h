@@ -80,7 +80,7 @@ struct cilqr_handle {
   int share_off;       // environment CILQR_NO_SHARE_KERNEL at create: static obstacles on one wavefront per solve at every batch size (A/B, tests)
   int tab_budget_kb;   // 0 = automatic (cilqr_api.cpp, lds_table_budget); else KiB (environment CILQR_LDS_TABLE_KB at create: A/B)
   int share_w;         // 0 = automatic (three wavefronts up to one solve per SIMD, two beyond); else 2 or 3 (environment CILQR_SHARE_W at create)
-  int share_max;       // largest batch on the shared-phase-L kernel (cilqr_solve_share_kernel): the SIMD count; CILQR_SHARE_MAX_B overrides
+  int share_max;       // -1: the largest batch on the shared-phase-L kernel follows the horizon (cilqr_api.cpp, pick_share); CILQR_SHARE_MAX_B overrides
   int pair_on;         // environment CILQR_PAIR_KERNEL at create: the two-wavefront kernel for batches up to one solve per SIMD
                        // (a measured negative result, DESIGN.md §5: kept for the A/B of tools/pair_ab.py and its tests, off by default)
   int force_g;       // 0 = automatic; else 1,2,4,8,16,32 or 64 (test hook: environment CILQR_FORCE_G at create)

@@ -1644,7 +1644,7 @@ __global__ __launch_bounds__(W * WAVE, 2) void cilqr_solve_split_kernel(SolveArg
 // test_share_kernel_changes_no_bit).  Horizons up to 63 (one state per lane), obstacle table in LDS, no map, early-exit mode.
 // DIAG: a.diag[b] = {prologue, L (main's share + the wait at barrier A + the combine), R, F, epilogue, #L, #R, total, aux: busy
 // ticks, aux: calls, main: ticks waiting at barrier A, 0…}.
-// LONG: horizons 64 … 127, two steps per lane (two wavefronts only: the registers of a second step do not fit three wavefronts per SIMD).
+// LONG: horizons 65 … 127, two steps per lane (two wavefronts only: the registers of a second step do not fit three wavefronts per SIMD).
 template <int W, bool LONG, bool DIAG>
 __global__ __launch_bounds__(W * WAVE, W) void cilqr_solve_share_kernel(SolveArgs a) {  // (W wavefronts per SIMD: ≤ 256 / 168 vector registers)
   static_assert(!(LONG && W != 2), "the long-horizon form is built for two wavefronts");
@@ -1766,7 +1766,8 @@ __global__ __launch_bounds__(W * WAVE, W) void cilqr_solve_share_kernel(SolveArg
         double sA = 0.0, cA = 1.0;
         if (lane <= N) sincos_loop(Xa[lane * XR + 3], sA, cA);  // (headings within sincos_loop's range: rollout_fast, MAX_TURN)
         cn = __shfl_down(cA, 1, WAVE);
-        const double sn = __shfl_down(sA, 1, WAVE);
+        double sn = __shfl_down(sA, 1, WAVE);
+        if (N == WAVE && lane == WAVE - 1 && wave == W - 1) sincos_loop(Xa[N * XR + 3], sn, cn);  // (N = 64: the last state has no lane of its own)
         if (lane < N) aux_step(lane, cA, sA, cn, sn);
       } else {         // horizons up to 127, two steps per lane: the last aux wavefront evaluates the next heading itself
         for (int t = lane; t < N; t += WAVE) {
@@ -2153,7 +2154,7 @@ hipError_t launch_solve_wave(const SolveArgs& a, hipStream_t stream) {
   if (tab_lds && a.pair == 1 && !a.unc.layer && (a.flags & CILQR_FLAG_FAITHFUL_ITERS) == 0)
     return a.diag ? launch_two_wavefronts<true>(a, tab_bytes, stream) : launch_two_wavefronts<false>(a, tab_bytes, stream);
   if (a.pair >= 2 && a.n_samples == 0 && solve_share_applies(a.N, a.M, a.kp.n_samples, a.tab_budget) && !a.unc.layer && (a.flags & CILQR_FLAG_FAITHFUL_ITERS) == 0) {
-    if (a.N >= WAVE) return a.diag ? launch_shared_L<2, true, true>(a, tab_bytes, stream) : launch_shared_L<2, true, false>(a, tab_bytes, stream);
+    if (a.N > WAVE) return a.diag ? launch_shared_L<2, true, true>(a, tab_bytes, stream) : launch_shared_L<2, true, false>(a, tab_bytes, stream);
     if (a.pair == 3 && a.M >= 2) return a.diag ? launch_shared_L<3, false, true>(a, tab_bytes, stream) : launch_shared_L<3, false, false>(a, tab_bytes, stream);
     return a.diag ? launch_shared_L<2, false, true>(a, tab_bytes, stream) : launch_shared_L<2, false, false>(a, tab_bytes, stream);
   }
