@@ -520,13 +520,14 @@ def test_share_kernel_changes_no_bit(cilqr, oracle, monkeypatch, N, M, B):
     _compare({k: v[idx] for k, v in got.items()}, _oracle_batch(oracle, N, sub), TIGHT, "two wavefronts sharing phase L")
 
 
-def test_share_kernel_weights_warm_starts_and_hand_over(cilqr, oracle, monkeypatch):
+@pytest.mark.parametrize("M", [6, 30])
+def test_share_kernel_weights_warm_starts_and_hand_over(cilqr, oracle, monkeypatch, M):
     """The shared-phase-L kernel with per-obstacle weights, warm-started (random) controls, a moving obstacle, and solves that it hands
     to the GENERAL kernel (a NaN start, a heading beyond the in-loop sincos range, a turn of more than 1/4 rad per step): the bits of
     the one-wavefront kernel, NaNs included, and the oracle's results where it has finite ones.  Where the kernel does not apply
     (N = 128: two steps per lane no longer cover the horizon; a batch beyond two solves per SIMD) the library says so and runs one wavefront."""
     from cilqr_amd import scenes
-    N, M, B = 50, 6, 160
+    N, B = 50, 160  # (M = 30: 87 KB of LDS per solve — the table only fits because one solve has a CU to itself; both kernels of the pair need their limit raised)
     p = cilqr.default_params(N)
     sc = scenes.make_static(B, N, M, p, 7377)
     rng = np.random.default_rng(7377)
