@@ -371,8 +371,8 @@ int cilqr_solve_family(const cilqr_handle* h, int B, int N, int M);
 /* Wavefronts per solve of cilqr_solve_batch(_device) on the one-wavefront family: 2 or 3 where further wavefronts take the obstacle,
  * Jacobian and control-barrier terms of phase L while the first searches the closest path samples (cilqr_solve_share_kernel, DESIGN.md
  * §4.2: three up to three quarters of a solve per SIMD, at least two obstacles and N ≤ 64, two up to two solves per SIMD and N ≤ 127; obstacle
- * table in LDS — a solve's LDS share grows where fewer solves share a CU —, no
- * uncertainty map; results bit-identical to the one-wavefront kernel; CILQR_NO_SHARE_KERNEL in the environment at create switches it
+ * table in LDS — a solve's LDS share grows where fewer solves share a CU; with an uncertainty map set, whose term then goes to the
+ * last of the further wavefronts: three up to half a solve per SIMD, two up to one; results bit-identical to the one-wavefront kernel; CILQR_NO_SHARE_KERNEL in the environment at create switches it
  * off, CILQR_SHARE_W = 2 or 3 fixes the number), else 1 (also for every shape cilqr_solve_family sends to the grouped family).
  * CILQR_FLAG_FAITHFUL_ITERS always runs on one.  Negative: error code. */
 int cilqr_solve_wavefronts(const cilqr_handle* h, int B, int N, int M);

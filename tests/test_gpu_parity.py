@@ -1935,6 +1935,43 @@ def test_solve_with_uncertainty_map_matches_oracle(cilqr, oracle, G, monkeypatch
     assert np.abs(got["U"] - plain["U"]).max() > 1e-3  # the map term is live
 
 
+@pytest.mark.parametrize("N,M,B,W", [(50, 4, 192, 3), (50, 4, 700, 2), (30, 0, 40, 3), (80, 6, 100, 2), (50, 4, 1500, 1)])
+def test_share_kernel_with_uncertainty_map_changes_no_bit(cilqr, oracle, monkeypatch, N, M, B, W):
+    """With a map set the shared-phase-L kernel gives the map term to its last aux wavefront (three wavefronts per solve up to half a
+    solve per SIMD, two up to one, one beyond; horizons beyond 64 on two): U, X, J, iterations and exits bit-identical to the
+    one-wavefront kernel's with the same map, a shared map and per-solve maps with per-solve poses."""
+    import torch
+    from cilqr_amd import scenes
+    p = _unc_params(cilqr, N)
+    sc = scenes.make_static(B, N, M, p, 4411)
+    geom, layer = _unc_layer(oracle, 2)
+    g = cilqr.map_geom(*geom)
+    rng = np.random.default_rng(4412)
+    poses = np.stack([rng.uniform(-2, 2, B), rng.uniform(-1, 1, B), rng.uniform(-0.2, 0.2, B)], 1)
+    dev = torch.device("cuda", 0)
+    d_layer = torch.from_numpy(np.ascontiguousarray(np.asfortranarray(layer, dtype=np.float32).flatten(order="F"))).to(dev)
+    d_poses = torch.from_numpy(poses).to(dev)
+    out = {}
+    for name in ("share", "one"):
+        if name == "one":
+            monkeypatch.setenv("CILQR_NO_SHARE_KERNEL", "1")
+        s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=max(M, 1), device=0)
+        monkeypatch.delenv("CILQR_NO_SHARE_KERNEL", raising=False)
+        try:
+            s.set_uncertainty_map(layer, g, (-1.0, 0.4, 0.05), (3, 3))
+            w = s.solve_wavefronts(B, N, M)
+            shared = _gpu_batch(s, sc)
+            s.set_uncertainty_map_device(d_layer.data_ptr(), g, (0.0, 0.0, 0.0), (2, 3), layer_stride=0, poses_ptr=d_poses.data_ptr())
+            per_pose = _gpu_batch(s, sc)
+        finally:
+            s.close()
+        out[name] = (w, shared, per_pose)
+    assert (out["share"][0], out["one"][0]) == (W, 1)
+    _same_bits(out["share"][1], out["one"][1], "map set, %d wavefronts against one" % W)
+    _same_bits(out["share"][2], out["one"][2], "per-solve poses, %d wavefronts against one" % W)
+    assert np.isfinite(out["share"][1]["U"]).all()
+
+
 def test_solve_with_per_solve_maps_and_poses(cilqr, oracle):
     """The device form with one layer and one map pose per solve (a scenario batch), wavefront family and sampled obstacles
     on top: every solve reads its own map."""

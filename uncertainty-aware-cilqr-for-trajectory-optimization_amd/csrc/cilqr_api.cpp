@@ -127,6 +127,8 @@ static int pick_share(const cilqr_handle* h, int B, int N, int M) {
   const long cap = h->share_max >= 0 ? (long)h->share_max : (long)q * h->simds / 4;
   if (h->share_off || B > cap) return 0;
   const int w = h->share_w ? h->share_w : (4 * B <= 3 * h->simds ? 3 : 2);
+  if (h->unc.layer)  // a map set: its term on the last aux wavefront; two wavefronts per SIMD, so three per solve up to half a solve per SIMD
+    return N > 64 ? 2 : h->share_w ? h->share_w : (2 * B <= h->simds ? 3 : (B <= h->simds ? 2 : 0));
   return w == 3 && (M < 2 || N > 64) ? 2 : w;  // (horizons 65 … 127: two steps per lane, built for two wavefronts)
 }
 
@@ -479,7 +481,7 @@ int cilqr_solve_wavefronts(const cilqr_handle* h, int B, int N, int M) {
   if (!h || B < 0 || N < 1 || M < 0) return fail(CILQR_ERR_ARG, "cilqr_solve_wavefronts: bad argument");
   if (pick_group_lanes(h, B, N, M) != 64) return 1;
   const int w = pick_share(h, B, N, M);
-  return w && !h->pair_on && !h->unc.layer && cilqr::solve_share_applies(N, M, h->kp.n_samples, lds_table_budget(h, B)) ? w : 1;
+  return w && !h->pair_on && cilqr::solve_share_applies(N, M, h->kp.n_samples, lds_table_budget(h, B)) ? w : 1;
 }
 
 int cilqr_solve_sampled_wavefronts(const cilqr_handle* h, int B, int N, int n_obs) {

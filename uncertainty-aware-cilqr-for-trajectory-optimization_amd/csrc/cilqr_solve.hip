@@ -1645,8 +1645,14 @@ __global__ __launch_bounds__(W * WAVE, 2) void cilqr_solve_split_kernel(SolveArg
 // DIAG: a.diag[b] = {prologue, L (main's share + the wait at barrier A + the combine), R, F, epilogue, #L, #R, total, aux: busy
 // ticks, aux: calls, main: ticks waiting at barrier A, 0…}.
 // LONG: horizons 65 … 127, two steps per lane (two wavefronts only: the registers of a second step do not fit three wavefronts per SIMD).
-template <int W, bool LONG, bool DIAG>
-__global__ __launch_bounds__(W * WAVE, W) void cilqr_solve_share_kernel(SolveArgs a) {  // (W wavefronts per SIMD: ≤ 256 / 168 vector registers)
+// UNC: an uncertainty map is set (cilqr_set_uncertainty_map*) — the reference's own mode of operation.  The map term (footprint probes,
+// bilinear lookups, one exponential each: ≈ 4 k ticks per call, as much as all obstacles of config 2) goes to the LAST aux wavefront,
+// beside the Jacobians (and, with three wavefronts, the control barrier); the obstacle terms — all of them, even and odd chain — to
+// wavefront 1.  It leaves its five scaled sums per step in LDS and main adds them to l_x / l_xx behind the obstacle sums, the order of
+// the one-wavefront kernel (unc_cost_add adds w·vx, w·mx to the finished record, I/Constraints.cpp:188-201).  Two wavefronts per SIMD
+// (the map code needs more than 168 registers), so three wavefronts per solve up to half a solve per SIMD.
+template <int W, bool LONG, bool DIAG, bool UNC = false>
+__global__ __launch_bounds__(W * WAVE, UNC ? 2 : W) void cilqr_solve_share_kernel(SolveArgs a) {  // (W wavefronts per SIMD: ≤ 256 / 168 vector registers)
   static_assert(!(LONG && W != 2), "the long-horizon form is built for two wavefronts");
   constexpr int STEPS = LONG ? 2 : 1;  // steps per lane
   unsigned long long tk0 = 0, tk = 0, c_pro = 0, c_L = 0, c_R = 0, c_F = 0, n_L = 0, n_R = 0, c_wait = 0;
@@ -1672,7 +1678,8 @@ __global__ __launch_bounds__(W * WAVE, W) void cilqr_solve_share_kernel(SolveArg
   double* cst = rec + N * RECF;
   double* tab = cst + RCST;
   double* part = tab + (size_t)M * TABF * N;  // [W - 1][N][5]: the aux wavefronts' sums of a step's obstacle terms
-  double* ctl = part + (((W - 1) * 5 * N + 1) & ~1);  // {command word, dmax, curvature bound, -}
+  double* umap = part + (size_t)(W - 1) * 5 * N;      // UNC: [N][5], the map term's scaled sums of a step
+  double* ctl = part + ((((W - 1) + (UNC ? 1 : 0)) * 5 * N + 1) & ~1);  // {command word, dmax, curvature bound, -}
   int* const cmd = reinterpret_cast<int*>(ctl);
   double* fwd = a.fwd + (size_t)b * (N + 1) * FREC;
 
@@ -1685,6 +1692,8 @@ __global__ __launch_bounds__(W * WAVE, W) void cilqr_solve_share_kernel(SolveArg
   if (tid < 16 && (tid & 7) < 5) cst[(tid & 7) + (tid >> 3) * RECF] = (tid & 7) == 0 ? 0.0 : (tid & 7) == 1 ? 1.0 : (tid & 7) == 2 ? kp.dt : (tid & 7) == 3 ? kp.w_vel * 2 : 2.0;
   if (tid == 0) cmd[0] = 0;
   const double* wts = a.obs_weight ? a.obs_weight + (size_t)b * M : nullptr;
+  UncPose upose{0, 0, 1, 0};
+  if (UNC) upose = unc_pose(a.unc, b);
   __syncthreads();  // the controls are in LDS
   bool handover = false;
   if (wave == 0) {
@@ -1735,30 +1744,38 @@ __global__ __launch_bounds__(W * WAVE, W) void cilqr_solve_share_kernel(SolveArg
         const double u0 = Ua[2 * t], u1 = Ua[2 * t + 1];
         StepSums s5{0.0, 0.0, 0.0, 0.0, 0.0};
         const ObsConsts oc = make_obs_consts(kpl, xr[0], xr[1], cA, sA);
-        if (W == 2) {  // every entry: even and odd chains, as lin_step forms them
+        if (W == 2 || (UNC && wave == 1)) {  // every entry: even and odd chains, as lin_step forms them
           obstacle_loop<true, false, true>(oc, M, TabSource<false>{tab, wts, N, kpl.w_obstacle}.at(t), s5);
-        } else {       // this wavefront's chain: entries wave - 1, wave + 1, …
+        } else if (!UNC) {                   // this wavefront's chain: entries wave - 1, wave + 1, …
           const int first = wave - 1;
           obstacle_loop<true, false, true, false>(oc, (M - first + 1) / 2, TabObstaclesStrided{tab + (size_t)t * TABF, wts, N, first, 2, kpl.w_obstacle}, s5);
         }
         double* q = part + ((size_t)(wave - 1) * N + t) * 5;
         q[0] = s5.lx0; q[1] = s5.lx1; q[2] = s5.h00; q[3] = s5.h01; q[4] = s5.h11;
-        if (wave == W - 1) {  // the last aux wavefront: Jacobians, and with W = 3 the control barrier (with W = 2: on main)
+        if (UNC && wave == W - 1) {  // the map term, from zero: w·vx, w·mx exactly as unc_cost_add would add them to a finished record
+          double g0 = 0.0, g1 = 0.0, h00 = 0.0, h01 = 0.0, h11 = 0.0;
+          unc_cost_add(phase_args().unc, upose, b, xr[0], xr[1], cA, sA, g0, g1, h00, h01, h11);
+          double* qu = umap + (size_t)t * 5;
+          qu[0] = g0; qu[1] = g1; qu[2] = h00; qu[3] = h01; qu[4] = h11;
+        }
+        if (wave == W - 1) {  // the last aux wavefront: Jacobians
           Rec c;
           ab_terms(kpl, u0, Xa[(t + 1) * XR + 2], cn, sn, c);
           double* r = rec + t * RECF;
           r[10] = c.al; r[11] = c.be; r[12] = c.ga; r[13] = c.de;
-          if (W == 3) {
-            double a1, a2, a3, a4;
-            ctrl_args(kpl, u0, u1, xr[2], a1, a2, a3, a4);
-            const double e1 = exp_fast(a1);
-            const double e2 = exp_fast(a2);
-            const double e3 = exp_fast(a3);
-            const double e4 = exp_fast(a4);
-            ctrl_terms(kpl, u0, u1, e1, e2, e3, e4, c);
-            const double ih = 2.0 / kpl.dt;  // production records: acceleration in units of (dt/2)·u0 (riccati_mfma)
-            r[6] = c.lu0 * ih; r[7] = c.lu1; r[8] = c.luu0 * (ih * ih); r[9] = c.luu1;
-          }
+        }
+        if (W == 3 && wave == (UNC ? 1 : 2)) {  // the control barrier: with W = 2 on main; with a map set beside the obstacles (the map term is the longer share)
+          Rec c;
+          double a1, a2, a3, a4;
+          ctrl_args(kpl, u0, u1, xr[2], a1, a2, a3, a4);
+          const double e1 = exp_fast(a1);
+          const double e2 = exp_fast(a2);
+          const double e3 = exp_fast(a3);
+          const double e4 = exp_fast(a4);
+          ctrl_terms(kpl, u0, u1, e1, e2, e3, e4, c);
+          double* r = rec + t * RECF;
+          const double ih = 2.0 / kpl.dt;  // production records: acceleration in units of (dt/2)·u0 (riccati_mfma)
+          r[6] = c.lu0 * ih; r[7] = c.lu1; r[8] = c.luu0 * (ih * ih); r[9] = c.luu1;
         }
       };
       double cn = 0.0;
@@ -1849,13 +1866,17 @@ __global__ __launch_bounds__(W * WAVE, W) void cilqr_solve_share_kernel(SolveArg
         if (t < N) {
           const double* q = part + (size_t)t * 5;
           StepSums s5{q[0], q[1], q[2], q[3], q[4]};
-          if (W == 3) {  // odd sums onto even sums: obstacle_loop's last statement
+          if (W == 3 && !UNC) {  // odd sums onto even sums: obstacle_loop's last statement
             const double* qo = q + (size_t)N * 5;
             s5.lx0 += qo[0]; s5.lx1 += qo[1]; s5.h00 += qo[2]; s5.h01 += qo[3]; s5.h11 += qo[4];
           }
           double* r = rec + t * RECF;
           double lx0, lx1, l00, l01, l11;
           state_terms(kpl, dx[c2], dy[c2], s5, lx0, lx1, l00, l01, l11);
+          if (UNC) {  // the map term joins the finished sums (I/Constraints.cpp:188-201)
+            const double* qu = umap + (size_t)t * 5;
+            lx0 += qu[0]; lx1 += qu[1]; l00 += qu[2]; l01 += qu[3]; l11 += qu[4];
+          }
           r[0] = lx0; r[1] = lx1; r[2] = lx2[c2]; r[3] = l00; r[4] = l01; r[5] = l11;
         }
       }
@@ -2035,21 +2056,29 @@ hipError_t launch_two_wavefronts(const SolveArgs& a, size_t tab_bytes, hipStream
   hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, 1, true, false>), dim3(a.B), dim3(WAVE), lds_general, stream, a);
   return hipGetLastError();
 }
-// The shared-phase-L kernel (table in LDS, no map, early exit, N ≤ 127) with the GENERAL kernel of the one-wavefront family behind it.
-template <int W, bool LONG, bool DIAG>
+// The shared-phase-L kernel (table in LDS, early exit, N ≤ 127; with or without an uncertainty map) with the GENERAL kernel of the
+// one-wavefront family behind it.
+template <int W, bool LONG, bool DIAG, bool UNC>
 hipError_t launch_shared_L(const SolveArgs& a, size_t tab_bytes, hipStream_t stream) {
-  const size_t lds_fast = core_lds_bytes(a.N, a.kp.n_samples, true) + tab_bytes + ((((size_t)(W - 1) * 5 * a.N + 1) & ~(size_t)1) + 4) * sizeof(double);
+  const size_t lds_fast = core_lds_bytes(a.N, a.kp.n_samples, true) + tab_bytes +
+                          ((((size_t)((W - 1) + (UNC ? 1 : 0)) * 5 * a.N + 1) & ~(size_t)1) + 4) * sizeof(double);
   const size_t lds_general = core_lds_bytes(a.N, a.kp.n_samples, false) + tab_bytes;
   if (lds_fast > 64 * 1024 || lds_general > 64 * 1024) {  // few solves per CU with large tables: more than the default 64 KiB of dynamic LDS
     const int want = (int)(lds_fast > lds_general ? lds_fast : lds_general);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cilqr_solve_share_kernel<W, LONG, DIAG>), hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cilqr_solve_share_kernel<W, LONG, DIAG, UNC>), hipFuncAttributeMaxDynamicSharedMemorySize, want);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cilqr_solve_kernel<DIAG, 1, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, want);
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cilqr_solve_kernel<DIAG, 1, true, UNC>), hipFuncAttributeMaxDynamicSharedMemorySize, want);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((cilqr_solve_share_kernel<W, LONG, DIAG>), dim3(a.B), dim3(W * WAVE), lds_fast, stream, a);
-  hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, 1, true, false>), dim3(a.B), dim3(WAVE), lds_general, stream, a);
+  hipLaunchKernelGGL((cilqr_solve_share_kernel<W, LONG, DIAG, UNC>), dim3(a.B), dim3(W * WAVE), lds_fast, stream, a);
+  hipLaunchKernelGGL((cilqr_solve_kernel<DIAG, 1, true, UNC>), dim3(a.B), dim3(WAVE), lds_general, stream, a);
   return hipGetLastError();
+}
+template <bool DIAG, bool UNC>
+hipError_t launch_shared_L_by_shape(const SolveArgs& a, size_t tab_bytes, hipStream_t stream) {
+  if (a.N > WAVE) return launch_shared_L<2, true, DIAG, UNC>(a, tab_bytes, stream);
+  if (a.pair == 3 && (UNC || a.M >= 2)) return launch_shared_L<3, false, DIAG, UNC>(a, tab_bytes, stream);
+  return launch_shared_L<2, false, DIAG, UNC>(a, tab_bytes, stream);
 }
 template <bool DIAG, int TAB>
 hipError_t launch_pair(const SolveArgs& a, size_t extra, hipStream_t stream) {
@@ -2153,10 +2182,9 @@ hipError_t launch_solve_wave(const SolveArgs& a, hipStream_t stream) {
   const size_t extra = tab_lds ? tab_bytes : 0;
   if (tab_lds && a.pair == 1 && !a.unc.layer && (a.flags & CILQR_FLAG_FAITHFUL_ITERS) == 0)
     return a.diag ? launch_two_wavefronts<true>(a, tab_bytes, stream) : launch_two_wavefronts<false>(a, tab_bytes, stream);
-  if (a.pair >= 2 && a.n_samples == 0 && solve_share_applies(a.N, a.M, a.kp.n_samples, a.tab_budget) && !a.unc.layer && (a.flags & CILQR_FLAG_FAITHFUL_ITERS) == 0) {
-    if (a.N > WAVE) return a.diag ? launch_shared_L<2, true, true>(a, tab_bytes, stream) : launch_shared_L<2, true, false>(a, tab_bytes, stream);
-    if (a.pair == 3 && a.M >= 2) return a.diag ? launch_shared_L<3, false, true>(a, tab_bytes, stream) : launch_shared_L<3, false, false>(a, tab_bytes, stream);
-    return a.diag ? launch_shared_L<2, false, true>(a, tab_bytes, stream) : launch_shared_L<2, false, false>(a, tab_bytes, stream);
+  if (a.pair >= 2 && a.n_samples == 0 && solve_share_applies(a.N, a.M, a.kp.n_samples, a.tab_budget) && (a.flags & CILQR_FLAG_FAITHFUL_ITERS) == 0) {
+    if (a.unc.layer) return a.diag ? launch_shared_L_by_shape<true, true>(a, tab_bytes, stream) : launch_shared_L_by_shape<false, true>(a, tab_bytes, stream);
+    return a.diag ? launch_shared_L_by_shape<true, false>(a, tab_bytes, stream) : launch_shared_L_by_shape<false, false>(a, tab_bytes, stream);
   }
   if (a.diag) return tab_lds ? launch_pair<true, 1>(a, extra, stream) : launch_pair<true, 0>(a, extra, stream);
   return tab_lds ? launch_pair<false, 1>(a, extra, stream) : launch_pair<false, 0>(a, extra, stream);
