@@ -3,10 +3,15 @@ from a seeded generator, every draw through the C-ABI against the oracle.  The f
 behaviours; this sweep looks for what nobody thought of naming — in particular in the paths added in round 3 (lane sharing in
 the grouped family, two and four wavefronts per sampled solve, two and three per static-obstacle solve), whose lane ↔ step maps
 depend on the shape in many ways."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+# CILQR_FUZZ_SCALE=n in the environment: n times as many seeded draws per test (a one-off wider sweep; the committed default is 1)
+SCALE = max(1, int(os.environ.get("CILQR_FUZZ_SCALE", "1")))
 
 TIGHT = 1e-9
 
@@ -31,7 +36,7 @@ def _tweak(p, rng):
     return p
 
 
-@pytest.mark.parametrize("seed", range(18))
+@pytest.mark.parametrize("seed", range(18 * SCALE))
 def test_random_static_scenes(cilqr, oracle, monkeypatch, seed):
     from cilqr_amd import scenes
     rng = np.random.default_rng(9100 + seed)
@@ -74,7 +79,7 @@ def test_random_static_scenes(cilqr, oracle, monkeypatch, seed):
     _compare(got, want, "seed %d: N=%d M=%d B=%d G=%d share=%s" % (seed, N, M, B, G, share))
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 * SCALE))
 def test_random_static_scenes_wavefront_family(cilqr, oracle, monkeypatch, seed):
     """The one-wavefront family on its own: one, two or three wavefronts per solve (cilqr_solve_share_kernel where the shape allows it,
     cilqr_solve_kernel otherwise), horizons up to the 63 the shared kernel takes and a little beyond, tables that fit LDS and tables
@@ -119,7 +124,7 @@ def test_random_static_scenes_wavefront_family(cilqr, oracle, monkeypatch, seed)
     _compare(got, want, "seed %d: N=%d M=%d B=%d share=%s -> %d wavefront(s) per solve" % (seed, N, M, B, share, w))
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(8 * SCALE))
 def test_random_sampled_scenes(cilqr, oracle, monkeypatch, seed):
     from cilqr_amd import scenes
     rng = np.random.default_rng(9300 + seed)
