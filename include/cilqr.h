@@ -123,6 +123,10 @@ typedef enum cilqr_exit {
 /* Execute the backward/forward passes of rejected iterations exactly as the reference loop does
  * instead of stopping at the first rejection (results are identical). */
 #define CILQR_FLAG_FAITHFUL_ITERS 1u
+/* Test hook: every solve is handed to the GENERAL kernels (branching passes, library-range sincos of every heading, the regularised
+ * Q_uu inverse in its eigenvalue-clamping form and the value update as the reference's direct product K' Q_uu) — the path
+ * that otherwise only solves take which the production kernels do not cover.  Same results to rounding, several times slower. */
+#define CILQR_FLAG_GENERAL_ONLY 2u
 
 typedef struct cilqr_handle cilqr_handle;
 

@@ -79,6 +79,27 @@ def test_early_exit_equals_reference_loop(cilqr, solver):
         assert np.array_equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("G", [0, 8])
+def test_general_only_flag(cilqr, oracle, monkeypatch, G):
+    """CILQR_FLAG_GENERAL_ONLY hands every solve to the GENERAL kernels (library-range sincos, eigenvalue-clamping inverse, the value
+    update as the reference's direct product): same accept / reject paths and results to rounding as the production kernels and the
+    oracle, both families — the path that otherwise only runs for the rare solve the production kernels do not cover."""
+    from cilqr_amd import scenes
+    if G:
+        monkeypatch.setenv("CILQR_FORCE_G", str(G))
+    N, M, B = 50, 4, 192
+    p = cilqr.default_params(N)
+    sc = scenes.make_static(B, N, M, p, 8123)
+    s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M, device=0)
+    try:
+        prod = _gpu_batch(s, sc)
+        gen = _gpu_batch(s, sc, flags=cilqr.FLAG_GENERAL_ONLY)
+    finally:
+        s.close()
+    _compare(gen, prod, 1e-10, "GENERAL kernels only against the production kernels G=%d" % G)
+    _compare(gen, _oracle_batch(oracle, N, sc), TIGHT, "GENERAL kernels only G=%d" % G)
+
+
 @pytest.mark.parametrize("N,M,B,seed", [(30, 2, 128, 101), (80, 16, 128, 102), (50, 0, 64, 103), (1, 1, 8, 104), (64, 3, 32, 105),
                                         (65, 3, 32, 106), (7, 5, 16, 107), (2, 1, 8, 108), (3, 2, 8, 109)])
 def test_other_shapes(cilqr, oracle, solver, N, M, B, seed):

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("CILQR_LIB") or os.path.join(PKG_ROOT, "lib", "libcilq
 
 NX, NU, POLY = 4, 2, 6
 FLAG_FAITHFUL_ITERS = 1
+FLAG_GENERAL_ONLY = 2
 EXIT_TOLERANCE, EXIT_LAMBDA_MAX, EXIT_MAX_ITER, EXIT_NUMERIC = 0, 1, 2, 3
 
 # every symbol include/cilqr.h declares

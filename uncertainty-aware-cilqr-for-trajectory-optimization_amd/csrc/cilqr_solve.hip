@@ -930,7 +930,7 @@ __global__ __launch_bounds__(WAVE, UNC ? 1 : 2) void cilqr_solve_kernel(SolveArg
       if (lane == 0) store_state(Xa, i + 1, s);
     }
   } else {
-    handover = !rollout_fast(kp, N, a.x0 + (size_t)b * 4, Ua, Xa);
+    handover = !rollout_fast(kp, N, a.x0 + (size_t)b * 4, Ua, Xa) || (a.flags & CILQR_FLAG_GENERAL_ONLY) != 0;
   }
   __syncthreads();
 
@@ -1324,7 +1324,7 @@ __global__ __launch_bounds__(2 * WAVE) void cilqr_solve_pair_kernel(SolveArgs a)
   }
 
   // ---- the main wavefront ------------------------------------------------------------------------------------------------
-  bool handover = !rollout_fast<true>(kp, N, a.x0 + (size_t)b * 4, Ua, Xa);  // nominal rollout, I/iLQR.cpp:51-62
+  bool handover = !rollout_fast<true>(kp, N, a.x0 + (size_t)b * 4, Ua, Xa) || (a.flags & CILQR_FLAG_GENERAL_ONLY) != 0;  // nominal rollout, I/iLQR.cpp:51-62
   const int dbg = DIAG ? (int)((a.flags >> 8) & 3) : 0;  // (linearize_quads)
   if (dbg) __syncthreads();
   __syncthreads();  // B2
@@ -1476,7 +1476,7 @@ __global__ __launch_bounds__(W * WAVE, 2) void cilqr_solve_split_kernel(SolveArg
       }
       grid.dmax = wave_max_uniform(m);
     }
-    handover = !rollout_fast(kp, N, a.x0 + (size_t)b * 4, Ua, Xa);  // nominal rollout, I/iLQR.cpp:51-62
+    handover = !rollout_fast(kp, N, a.x0 + (size_t)b * 4, Ua, Xa) || (a.flags & CILQR_FLAG_GENERAL_ONLY) != 0;  // nominal rollout, I/iLQR.cpp:51-62
     if (handover && lane == 0) *reinterpret_cast<volatile int*>(cmd) = CMD_EXIT;
   }
   __syncthreads();  // the trajectory is in LDS
@@ -1697,7 +1697,7 @@ __global__ __launch_bounds__(W * WAVE, UNC ? 2 : W) void cilqr_solve_share_kerne
   __syncthreads();  // the controls are in LDS
   bool handover = false;
   if (wave == 0) {
-    handover = !rollout_fast(kp, N, a.x0 + (size_t)b * 4, Ua, Xa);  // nominal rollout, I/iLQR.cpp:51-62
+    handover = !rollout_fast(kp, N, a.x0 + (size_t)b * 4, Ua, Xa) || (a.flags & CILQR_FLAG_GENERAL_ONLY) != 0;  // nominal rollout, I/iLQR.cpp:51-62
     if (handover && lane == 0) *reinterpret_cast<volatile int*>(cmd) = CMD_EXIT;
   } else {
     // (W = 3: the two aux wavefronts share the table; samples and their largest step on the first)

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(WAVE) void cilqr_solve_groups_fast(SolveArgs a, dou
       dyn_step_loop(k, s, UF(L.ua(), i, 0), UF(L.ua(), i, 1), max_turn);
       store_state(L.xa(), i + 1, s);
     }
-    handover = !(th0_ok && max_turn <= MAX_TURN);
+    handover = !(th0_ok && max_turn <= MAX_TURN) || (a.flags & CILQR_FLAG_GENERAL_ONLY) != 0;
   }
   mem_sync();
 
