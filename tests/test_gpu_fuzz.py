@@ -125,6 +125,49 @@ def test_random_static_scenes_wavefront_family(cilqr, oracle, monkeypatch, seed)
 
 
 @pytest.mark.parametrize("seed", range(8 * SCALE))
+def test_random_static_scenes_with_map(cilqr, oracle, monkeypatch, seed):
+    """The same with an uncertainty map set (the reference's own mode: w_uncertainty·(vx, mx) into l_x, l_xx at every step,
+    I/Constraints.cpp:188-201): random probe grids and map poses, horizons up to 127, one to three wavefronts per solve (the map term
+    on the last aux wavefront of cilqr_solve_share_kernel) and the grouped family."""
+    from cilqr_amd import scenes
+    rng = np.random.default_rng(9800 + seed)
+    N, M, B = int(rng.integers(2, 128)), int(rng.integers(0, 9)), int(rng.integers(1, 400))
+    mode = ["rule", "2", "off", "g8"][seed % 4]
+    if mode == "g8":
+        monkeypatch.setenv("CILQR_FORCE_G", "8")
+    else:
+        monkeypatch.setenv("CILQR_FORCE_G", "64")
+        if mode == "off":
+            monkeypatch.setenv("CILQR_NO_SHARE_KERNEL", "1")
+        elif mode != "rule":
+            monkeypatch.setenv("CILQR_SHARE_W", mode)
+    p, po = cilqr.default_params(N), oracle.default_params(N)
+    for q in (p, po):
+        q.safe_length, q.safe_width = 1.1, 0.9  # ilqr/launch/Experiment.launch:7-8
+    sc = scenes.make_static(B, N, M, p, 9900 + seed)
+    if rng.random() < 0.5:
+        sc["U"] = sc["U"] + rng.normal(0.0, 0.1, sc["U"].shape)
+    geom = (30.0, 20.0, 0.2, 15.0, 0.0)
+    g, og = cilqr.map_geom(*geom), oracle.map_geom(*geom)
+    occ = scenes.make_occupancy(og.rows, og.cols, 700 + seed)
+    layer, _, _ = oracle.blur(np.nan_to_num(occ, nan=0.0), og, np.sin(0.1), np.cos(0.1), 0.16, 0.16, 0.017, threads=16)
+    layer[np.isnan(occ)] = np.nan
+    pose = (float(rng.uniform(-3, 3)), float(rng.uniform(-1, 1)), float(rng.uniform(-0.3, 0.3)))
+    probes = (int(rng.integers(1, 5)), int(rng.integers(1, 5)))
+    s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=max(M, 1), device=0)
+    try:
+        s.set_uncertainty_map(layer, g, pose, probes)
+        w = s.solve_wavefronts(B, N, M)
+        got = s.solve_batch(N, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"], sc["obs_weight"])
+    finally:
+        s.close()
+    um, keep = oracle.uncertainty_map(layer, og, pose, probes)
+    want = oracle.solve_batch_unc(po, N, M, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"], sc["obs_weight"], um,
+                                  threads=min(16, oracle.max_threads()))
+    _compare(got, want, "seed %d: N=%d M=%d B=%d probes %s mode %s -> %d wavefront(s) per solve" % (seed, N, M, B, probes, mode, w))
+
+
+@pytest.mark.parametrize("seed", range(8 * SCALE))
 def test_random_sampled_scenes(cilqr, oracle, monkeypatch, seed):
     from cilqr_amd import scenes
     rng = np.random.default_rng(9300 + seed)
