@@ -684,16 +684,19 @@ def test_split_kernel_against_one_wavefront_per_solve(cilqr, oracle, monkeypatch
     _compare({k: v[idx] for k, v in got.items()}, _oracle_batch(oracle, N, sub), TIGHT, "split kernel")
 
 
-def test_schedule_hint_changes_nothing_but_the_order(cilqr):
+@pytest.mark.parametrize("B", [3000, 1800])
+def test_schedule_hint_changes_nothing_but_the_order(cilqr, B):
     """A batch beyond one solve per SIMD is dispatched longest-first by the pass counts of the previous call (same batch size,
     same stream).  Every call must return bit-identical results — the first (identity order), the second (hinted) and a third
-    after the scenes were shuffled, when the hint is stale — and every solve must be written exactly once."""
+    after the scenes were shuffled, when the hint is stale — and every solve must be written exactly once.  B = 3000: one wavefront
+    per solve; B = 1800: two (cilqr_solve_share_kernel takes the dispatch order too)."""
     from cilqr_amd import scenes
-    B, N, M = 3000, 50, 4
+    N, M = 50, 4
     p = cilqr.default_params(N)
     sc = scenes.make_static(B, N, M, p, 403)
     s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=M, device=0)
     try:
+        assert s.solve_wavefronts(B, N, M) == (2 if B == 1800 else 1)
         first = _gpu_batch(s, sc)
         second = _gpu_batch(s, sc)
         perm = np.random.default_rng(5).permutation(B)
