@@ -1641,7 +1641,8 @@ __global__ __launch_bounds__(W * WAVE, 2) void cilqr_solve_split_kernel(SolveArg
 // decide a launch are the ones with every obstacle close (their aux wavefront took 6.1 k ticks per call where the mean took 4.3 k).
 // Bits: the statements are lin_step's, piece by piece (cilqr_device.hpp: obstacle sums from zero, state_terms), so a record does
 // not depend on which wavefront formed which slot — results are bit-identical to cilqr_solve_kernel's (tests/test_gpu_parity.py,
-// test_share_kernel_changes_no_bit).  Horizons up to 63 (one state per lane), obstacle table in LDS, no map, early-exit mode.
+// test_share_kernel_changes_no_bit).  Horizons up to 64 on one step per lane, up to 127 on two (LONG); obstacle table in LDS; with or
+// without an uncertainty map (UNC); early-exit mode.
 // DIAG: a.diag[b] = {prologue, L (main's share + the wait at barrier A + the combine), R, F, epilogue, #L, #R, total, aux: busy
 // ticks, aux: calls, main: ticks waiting at barrier A, 0…}.
 // LONG: horizons 65 … 127, two steps per lane (two wavefronts only: the registers of a second step do not fit three wavefronts per SIMD).
