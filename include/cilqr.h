@@ -381,7 +381,7 @@ int cilqr_solve_family(const cilqr_handle* h, int B, int N, int M);
  * CILQR_FLAG_FAITHFUL_ITERS always runs on one.  Negative: error code. */
 int cilqr_solve_wavefronts(const cilqr_handle* h, int B, int N, int M);
 /* The same for cilqr_solve_batch_sampled(_device): how many wavefronts share a solve's phase L on this handle — 1 (one wavefront
- * per solve: horizons beyond 64, a set uncertainty map, CILQR_NO_SPLIT_KERNEL), 2 or 4 (cilqr_solve_split_kernel, DESIGN.md
+ * per solve: horizons beyond 64, CILQR_NO_SPLIT_KERNEL), 2 or 4 (cilqr_solve_split_kernel, DESIGN.md
  * §4.1c).  CILQR_FLAG_FAITHFUL_ITERS always runs on one.  Negative: error code. */
 int cilqr_solve_sampled_wavefronts(const cilqr_handle* h, int B, int N, int n_obs);
 

@@ -684,6 +684,39 @@ def test_split_kernel_against_one_wavefront_per_solve(cilqr, oracle, monkeypatch
     _compare({k: v[idx] for k, v in got.items()}, _oracle_batch(oracle, N, sub), TIGHT, "split kernel")
 
 
+@pytest.mark.parametrize("B,W", [(160, 4), (300, 2)])
+def test_split_kernel_with_uncertainty_map(cilqr, oracle, monkeypatch, B, W):
+    """Sampled obstacles AND an uncertainty map — the reference planner's full mode: the split kernel gives the map term to its last
+    wavefront.  Against the one-wavefront kernel with the same map (CILQR_NO_SPLIT_KERNEL): same accept / reject paths, agreement to
+    rounding; against the oracle on the materialised scene with the same map: 1e-8."""
+    from cilqr_amd import scenes
+    N = 50
+    p, po = _unc_params(cilqr, N), _unc_params(oracle, N)
+    sc = scenes.make_c3(B, p, n_dyn=5, n_samples=6)
+    geom, layer = _unc_layer(oracle, 3)
+    g, og = cilqr.map_geom(*geom), oracle.map_geom(*geom)
+    pose = (-0.5, 0.3, 0.04)
+    out = {}
+    for name in ("split", "one"):
+        monkeypatch.setenv("CILQR_SPLIT_W", str(W)) if name == "split" else monkeypatch.setenv("CILQR_NO_SPLIT_KERNEL", "1")
+        s = cilqr.Solver(p, max_batch=B, max_horizon=N, max_obstacles=sc["M"], device=0)
+        monkeypatch.delenv("CILQR_SPLIT_W", raising=False)
+        monkeypatch.delenv("CILQR_NO_SPLIT_KERNEL", raising=False)
+        try:
+            s.set_uncertainty_map(layer, g, pose, (3, 3))
+            w = s.solve_sampled_wavefronts(B, N, 5)
+            out[name] = (w, s.solve_batch_sampled(N, sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["nom_pose"], sc["nom_dim"], sc["offsets"],
+                                                  sc["sample_weight"]))
+        finally:
+            s.close()
+    assert (out["split"][0], out["one"][0]) == (W, 1)
+    _compare(out["split"][1], out["one"][1], 1e-11, "split kernel with a map against one wavefront per solve")
+    um, keep = oracle.uncertainty_map(layer, og, pose, (3, 3))
+    want = oracle.solve_batch_unc(po, N, sc["M"], sc["x0"], sc["U"], sc["poly"], sc["xplan_fl"], sc["obs_pose"], sc["obs_dim"], sc["obs_weight"], um,
+                                  threads=min(16, oracle.max_threads()))
+    _compare(out["split"][1], want, 1e-8, "split kernel with a map")
+
+
 @pytest.mark.parametrize("B", [3000, 1800])
 def test_schedule_hint_changes_nothing_but_the_order(cilqr, B):
     """A batch beyond one solve per SIMD is dispatched longest-first by the pass counts of the previous call (same batch size,

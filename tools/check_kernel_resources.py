@@ -41,7 +41,7 @@ def check(notes):
     bad = []
     for name, r in sorted(notes.items()):
         m = re.search(r"cilqr_solve_kernelILb(\d)ELi(\d)ELb(\d)ELb(\d)E", name)
-        split = re.search(r"cilqr_solve_split_kernelILi(\d)ELb(\d)E", name)
+        split = re.search(r"cilqr_solve_split_kernelILi(\d)ELb(\d)ELb(\d)E", name)
         share = re.search(r"cilqr_solve_share_kernelILi(\d)ELb\dELb(\d)ELb(\d)E", name)
         if m:
             diag, tab, general, unc = (int(v) for v in m.groups())

@@ -487,7 +487,7 @@ int cilqr_solve_wavefronts(const cilqr_handle* h, int B, int N, int M) {
 int cilqr_solve_sampled_wavefronts(const cilqr_handle* h, int B, int N, int n_obs) {
   if (!h || B < 0 || N < 1 || n_obs < 1) return fail(CILQR_ERR_ARG, "cilqr_solve_sampled_wavefronts: bad argument");
   const int w = pick_split_wavefronts(h, B);
-  if (w < 2 || N > 64 || n_obs < w || h->unc.layer) return 1;
+  if (w < 2 || N > 64 || n_obs < w) return 1;
   return w >= 4 ? 4 : 2;
 }
 

@@ -1420,7 +1420,9 @@ __global__ __launch_bounds__(2 * WAVE) void cilqr_solve_pair_kernel(SolveArgs a)
 // W = wavefronts per solve (2 or 4): wavefront w takes the obstacles w, w + W, …; wavefront 0 adds the others' sums in the order 1, 2, 3.
 // DIAG: wavefront 0 stamps its phases into a.diag[b] = {prologue, L (its own share + the wait for the others + the combine), R, F,
 // epilogue, #L, #R, total}, as cilqr_solve_kernel does.
-template <int W, bool DIAG>
+// UNC: an uncertainty map is set — its term on the last wavefront, behind that wavefront's obstacle share; main adds the five scaled sums
+// per step behind all obstacle sums (the order of the one-wavefront kernel, where unc_cost_add joins the finished record).
+template <int W, bool DIAG, bool UNC = false>
 __global__ __launch_bounds__(W * WAVE, 2) void cilqr_solve_split_kernel(SolveArgs a) {  // (two wavefronts per SIMD: ≤ 256 vector registers)
   unsigned long long tk0 = 0, tk = 0, c_pro = 0, c_L = 0, c_R = 0, c_F = 0, n_L = 0, n_R = 0;
   if (DIAG) tk0 = tk = __builtin_readcyclecounter();
@@ -1446,7 +1448,8 @@ __global__ __launch_bounds__(W * WAVE, 2) void cilqr_solve_split_kernel(SolveArg
   double* off = cst + RCST;
   double* rmax = off + (size_t)M * NSMP * OFFF;
   double* part = rmax + 2 * M;                        // [W - 1][N][5]: the other wavefronts' sums of a step's obstacle terms
-  double* ctl = part + (((W - 1) * 5 * N + 1) & ~1);  // command word
+  double* umap = part + (size_t)(W - 1) * 5 * N;      // UNC: [N][5], the map term's scaled sums of a step
+  double* ctl = part + ((((W - 1) + (UNC ? 1 : 0)) * 5 * N + 1) & ~1);  // command word
   int* const cmd = reinterpret_cast<int*>(ctl);
   double* tab = a.obs_tab + (size_t)b * M * NOMF * N;
 
@@ -1465,6 +1468,8 @@ __global__ __launch_bounds__(W * WAVE, 2) void cilqr_solve_split_kernel(SolveArg
   if (tid < 16 && (tid & 7) < 5) cst[(tid & 7) + (tid >> 3) * RECF] = (tid & 7) == 0 ? 0.0 : (tid & 7) == 1 ? 1.0 : (tid & 7) == 2 ? kp.dt : (tid & 7) == 3 ? kp.w_vel * 2 : 2.0;
   if (tid == 0) cmd[0] = 0;
   sampled_prologue<W * WAVE>(a, kp, b, N, M, tab, off, rmax);
+  UncPose upose{0, 0, 1, 0};
+  if (UNC) upose = unc_pose(a.unc, b);
   __syncthreads();
   bool handover = false;
   if (wave == 0) {
@@ -1498,6 +1503,12 @@ __global__ __launch_bounds__(W * WAVE, 2) void cilqr_solve_split_kernel(SolveArg
         obstacle_loop<true, false, false, false>(make_obs_consts(kpl, xr[0], xr[1], xr[4], xr[5]), n_mine * NSMP, src.at(t), s5);
         double* q = part + ((size_t)(wave - 1) * N + t) * 5;
         q[0] = s5.lx0; q[1] = s5.lx1; q[2] = s5.h00; q[3] = s5.h01; q[4] = s5.h11;
+        if (UNC && wave == W - 1) {  // the map term, from zero: w·vx, w·mx as unc_cost_add would add them to a finished record
+          double g0 = 0.0, g1 = 0.0, h00 = 0.0, h01 = 0.0, h11 = 0.0;
+          unc_cost_add(phase_args().unc, upose, b, xr[0], xr[1], xr[4], xr[5], g0, g1, h00, h01, h11);
+          double* qu = umap + (size_t)t * 5;
+          qu[0] = g0; qu[1] = g1; qu[2] = h00; qu[3] = h01; qu[4] = h11;
+        }
       }
       __syncthreads();  // A: the sums are in LDS
       __syncthreads();  // B: wavefront 0 has decided, and, going on, has written the next trajectory
@@ -1533,6 +1544,10 @@ __global__ __launch_bounds__(W * WAVE, 2) void cilqr_solve_split_kernel(SolveArg
         for (int w = 1; w < W; ++w) {
           const double* q = part + ((size_t)(w - 1) * N + t) * 5;
           c.lx0 += q[0]; c.lx1 += q[1]; c.l00 += q[2]; c.l01 += q[3]; c.l11 += q[4];
+        }
+        if (UNC) {  // the map term joins the finished sums (I/Constraints.cpp:188-201)
+          const double* qu = umap + (size_t)t * 5;
+          c.lx0 += qu[0]; c.lx1 += qu[1]; c.l00 += qu[2]; c.l01 += qu[3]; c.l11 += qu[4];
         }
         double* r = rec + t * RECF;
         const double ih = 2.0 / kpl.dt;  // production records: acceleration in units of (dt/2)·u0 (riccati_mfma)
@@ -2159,21 +2174,24 @@ hipError_t launch_solve_wave(const SolveArgs& a, hipStream_t stream) {
   if (a.n_samples > 0) {  // sampled obstacles: offset records in LDS, nominal records in the global workspace
     const size_t extra = solve_sampled_lds_bytes(a.M, a.n_samples);
     if (lds + extra > SOLVE_LDS_MAX) return hipErrorInvalidValue;  // checked by the caller
-    if (a.split >= 2 && a.N <= WAVE && a.M >= a.split && !a.unc.layer && (a.flags & CILQR_FLAG_FAITHFUL_ITERS) == 0) {
+    if (a.split >= 2 && a.N <= WAVE && a.M >= a.split && (a.flags & CILQR_FLAG_FAITHFUL_ITERS) == 0) {
       // a.split wavefronts per solve share phase L (cilqr_solve_split_kernel); the GENERAL kernel of the one-wavefront family behind
       const int W = a.split >= 4 ? 4 : 2;
-      const size_t lds_fast = core_lds_bytes(a.N, a.kp.n_samples, true) + extra + ((((size_t)(W - 1) * 5 * a.N + 1) & ~(size_t)1) + 2) * sizeof(double);
+      const bool unc = a.unc.layer != nullptr;
+      const size_t lds_fast = core_lds_bytes(a.N, a.kp.n_samples, true) + extra + ((((size_t)((W - 1) + (unc ? 1 : 0)) * 5 * a.N + 1) & ~(size_t)1) + 2) * sizeof(double);
       const size_t lds_general = core_lds_bytes(a.N, a.kp.n_samples, false) + extra;
       if (lds_fast <= 64 * 1024 && lds_general <= 64 * 1024) {
+#define CILQR_SPLIT_LAUNCH(WW, DD, UU)                                                                                          \
+  hipLaunchKernelGGL((cilqr_solve_split_kernel<WW, DD, UU>), dim3(a.B), dim3(WW * WAVE), lds_fast, stream, a);                 \
+  hipLaunchKernelGGL((cilqr_solve_kernel<DD, 2, true, UU>), dim3(a.B), dim3(WAVE), lds_general, stream, a);
         if (a.diag) {
-          if (W == 4) hipLaunchKernelGGL((cilqr_solve_split_kernel<4, true>), dim3(a.B), dim3(4 * WAVE), lds_fast, stream, a);
-          else hipLaunchKernelGGL((cilqr_solve_split_kernel<2, true>), dim3(a.B), dim3(2 * WAVE), lds_fast, stream, a);
-          hipLaunchKernelGGL((cilqr_solve_kernel<true, 2, true, false>), dim3(a.B), dim3(WAVE), lds_general, stream, a);
+          if (unc) { if (W == 4) { CILQR_SPLIT_LAUNCH(4, true, true) } else { CILQR_SPLIT_LAUNCH(2, true, true) } }
+          else { if (W == 4) { CILQR_SPLIT_LAUNCH(4, true, false) } else { CILQR_SPLIT_LAUNCH(2, true, false) } }
         } else {
-          if (W == 4) hipLaunchKernelGGL((cilqr_solve_split_kernel<4, false>), dim3(a.B), dim3(4 * WAVE), lds_fast, stream, a);
-          else hipLaunchKernelGGL((cilqr_solve_split_kernel<2, false>), dim3(a.B), dim3(2 * WAVE), lds_fast, stream, a);
-          hipLaunchKernelGGL((cilqr_solve_kernel<false, 2, true, false>), dim3(a.B), dim3(WAVE), lds_general, stream, a);
+          if (unc) { if (W == 4) { CILQR_SPLIT_LAUNCH(4, false, true) } else { CILQR_SPLIT_LAUNCH(2, false, true) } }
+          else { if (W == 4) { CILQR_SPLIT_LAUNCH(4, false, false) } else { CILQR_SPLIT_LAUNCH(2, false, false) } }
         }
+#undef CILQR_SPLIT_LAUNCH
         return hipGetLastError();
       }
     }
